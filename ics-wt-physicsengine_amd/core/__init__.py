@@ -1,0 +1,12 @@
+"""GPU-backed stand-in for the hot path of ``wt_simulator.core``
+(export list modelled on /root/reference/src/wt_simulator/core/__init__.py:207-263,
+restricted to the multi-zone CSTR step and its batched pH solver)."""
+from .reactor import (BoundaryConditions, EnsembleState, IntegratedCSTR, PhysicsEngine,
+                      ReactorConfiguration, ReactorEnsemble, ReactorState, boundary_block)
+from .chemistry import AqueousChemistry, BufferSystem, solve_pH
+from .synthetic import make_ensemble
+from . import params
+
+__all__ = ["BoundaryConditions", "EnsembleState", "IntegratedCSTR", "PhysicsEngine", "ReactorConfiguration",
+           "ReactorEnsemble", "ReactorState", "boundary_block", "AqueousChemistry", "BufferSystem",
+           "solve_pH", "make_ensemble", "params"]

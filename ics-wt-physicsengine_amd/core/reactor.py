@@ -1,0 +1,441 @@
+"""Host-side mirror of the reference's reactor API over the HIP ensemble library.
+
+``IntegratedCSTR(config).step(dt, boundary) -> ReactorState`` keeps the
+reference's signature, field names, defaults and error behaviour
+(/root/reference/src/wt_simulator/core/reactor.py:52-186, 203-227, 450-541) so
+the unchanged sensor and Modbus layers can sit on top of it.
+``ReactorEnsemble`` is the batched front door the reference does not have: N
+independent reactors advanced by one kernel launch.  All arithmetic of the step
+runs in ``csrc/`` on the GPU; this module only packs SoA blocks, moves buffers
+and turns status bits back into the reference's exceptions and log lines.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import logging
+from dataclasses import dataclass, field, fields
+from types import SimpleNamespace
+from typing import Dict, Iterable, List, Optional, Sequence, Union
+
+import numpy as np
+
+from . import _native, params
+
+logger = logging.getLogger(__name__)
+
+ST_T_RANGE, ST_SOLVER_FAILED, ST_CLAMP_PH, ST_CLAMP_CL, ST_CLAMP_T, ST_T_RANGE_POST, ST_NONFINITE = (
+    1, 2, 4, 8, 16, 32, 64)
+
+_T_RANGE_TEXT = (
+    "Temperature {value}°C outside liquid water range [0.0, 100.0]°C. This indicates either:\n"
+    "  1. Invalid input data\n"
+    "  2. Numerical instability in ODE integration (reduce tolerances)\n"
+    "  3. System requires pressurized/supercooled water model")
+_SOLVER_FAILED_TEXT = "ODE solver failed: Required step size is less than spacing between numbers."
+
+
+# --------------------------------------------------------------------------- dataclasses
+@dataclass
+class ReactorConfiguration:
+    """Geometry, flow, chemistry and operating point of one CSTR (reactor.py:52-110)."""
+
+    volume: float = 1000.0            # [L]
+    height: float = 2.0               # [m]
+    diameter: float = 0.798           # [m]
+    n_zones: int = 5
+
+    flow_rate: float = 5.0            # [L/min]
+    turbulent_intensity: float = 0.15
+    recirculation_ratio: float = 5.0
+    impeller_speed: float = 60.0      # [rpm]
+    impeller_diameter: float = 0.3    # [m]
+    power_number: float = 5.0
+
+    initial_pH: float = 7.0
+    alkalinity: float = 100.0         # [mg/L as CaCO3]
+    total_carbonate: float = 2.0      # [mmol/L]
+
+    initial_chlorine: float = 2.0     # [mg/L]
+
+    temperature: float = 20.0         # [degC]
+    enable_thermal_stratification: bool = True
+
+    inlet_pH: float = 7.5
+    inlet_chlorine: float = 0.0
+    inlet_temperature: float = 20.0
+
+    def validate(self) -> None:
+        """Same checks, same exception types as reactor.py:91-110."""
+        calculated_volume = np.pi * (self.diameter / 2) ** 2 * self.height * 1000
+        volume_error = abs(calculated_volume - self.volume) / self.volume
+        if volume_error > 0.01:
+            raise ValueError(
+                f"Volume mismatch: specified {self.volume}L, "
+                f"calculated {calculated_volume:.1f}L from geometry. "
+                f"Error: {volume_error*100:.1f}%")
+        assert 0 < self.volume < 1e6, "Volume out of range"
+        assert 0 <= self.flow_rate < 1e5, "Flow rate out of range (use 0 for batch mode)"
+        assert 0 <= self.initial_pH <= 14, "pH out of range"
+        assert 0 <= self.initial_chlorine <= 10, "Chlorine out of range"
+        assert 0 <= self.temperature <= 40, "Temperature out of typical range"
+
+
+@dataclass
+class ReactorState:
+    """State of one reactor; every per-zone quantity is an array of length n_zones
+    (reactor.py:113-147)."""
+
+    time: float = 0.0
+    pH: np.ndarray = field(default_factory=lambda: np.full(5, 7.0))
+    chlorine: np.ndarray = field(default_factory=lambda: np.full(5, 2.0))
+    temperature: np.ndarray = field(default_factory=lambda: np.full(5, 20.0))
+    flow_rate: float = 5.0
+
+    H_concentration: np.ndarray = field(init=False)
+    density: np.ndarray = field(init=False)
+    chlorine_decay_rate: np.ndarray = field(init=False)
+
+    def __post_init__(self):
+        self.update_derived()
+
+    def update_derived(self):
+        self.H_concentration = 10 ** (-self.pH)
+        if not hasattr(self, "density"):
+            self.density = np.full_like(self.pH, 998.2)
+        if not hasattr(self, "chlorine_decay_rate"):
+            self.chlorine_decay_rate = np.full_like(self.pH, 0.0001)
+
+    def state_dict(self) -> Dict[str, object]:
+        """Plain-dict view (the 'state-dict API' BASELINE.json mentions)."""
+        return {f.name: getattr(self, f.name) for f in fields(self)}
+
+
+@dataclass
+class BoundaryConditions:
+    """Physical streams entering the tank during a step (reactor.py:150-186)."""
+
+    inlet_flow_rate: float = 5.0          # [L/min]
+    inlet_pH: float = 7.5
+    inlet_chlorine: float = 0.0           # [mg/L]
+    inlet_temperature: float = 20.0       # [degC]
+    acid_flow_rate: float = 0.0           # [L/min]
+    acid_concentration: float = 0.1       # [mol/L]
+    chlorine_flow_rate: float = 0.0       # [L/min]
+    chlorine_concentration: float = 50.0  # [mg/L]
+    ambient_temperature: float = 20.0     # [degC]
+    heat_loss_coefficient: float = 0.0    # [W/K]
+
+
+@dataclass
+class EnsembleState:
+    """State of N reactors; per-zone arrays are (N, n_zones), per-reactor arrays (N,)."""
+
+    time: np.ndarray
+    pH: np.ndarray
+    chlorine: np.ndarray
+    temperature: np.ndarray
+    flow_rate: np.ndarray
+    H_concentration: np.ndarray
+    density: np.ndarray
+    chlorine_decay_rate: np.ndarray
+    status: np.ndarray
+
+    def reactor(self, r: int) -> ReactorState:
+        s = ReactorState(time=float(self.time[r]), pH=self.pH[r].copy(), chlorine=self.chlorine[r].copy(),
+                         temperature=self.temperature[r].copy(), flow_rate=float(self.flow_rate[r]))
+        s.H_concentration = self.H_concentration[r].copy()
+        s.density = self.density[r].copy()
+        s.chlorine_decay_rate = self.chlorine_decay_rate[r].copy()
+        return s
+
+
+_CFG_FIELDS = [f.name for f in fields(ReactorConfiguration)]
+
+
+def _columns_from_configs(configs: Sequence[ReactorConfiguration]) -> Dict[str, np.ndarray]:
+    return {name: np.array([getattr(c, name) for c in configs]) for name in _CFG_FIELDS if name != "n_zones"}
+
+
+def boundary_block(boundaries, n_reactors: int) -> np.ndarray:
+    """(NB, N) float64 SoA block from a BoundaryConditions, a sequence of them, a
+    dict of columns (scalars broadcast) or a ready block."""
+    NB = params.NB
+    if isinstance(boundaries, np.ndarray):
+        blk = np.ascontiguousarray(boundaries, dtype=np.float64)
+        if blk.shape != (NB, n_reactors):
+            raise ValueError(f"boundary block must have shape {(NB, n_reactors)}, got {blk.shape}")
+        return blk
+    blk = np.empty((NB, n_reactors), dtype=np.float64)
+    if isinstance(boundaries, BoundaryConditions):
+        for i, name in enumerate(params.BOUNDARY_FIELDS):
+            blk[i] = getattr(boundaries, name)
+    elif isinstance(boundaries, dict):
+        defaults = BoundaryConditions()
+        for i, name in enumerate(params.BOUNDARY_FIELDS):
+            blk[i] = np.asarray(boundaries.get(name, getattr(defaults, name)), dtype=np.float64)
+    else:
+        seq = list(boundaries)
+        if len(seq) != n_reactors:
+            raise ValueError(f"expected {n_reactors} boundary conditions, got {len(seq)}")
+        for i, name in enumerate(params.BOUNDARY_FIELDS):
+            blk[i] = [getattr(b, name) for b in seq]
+    return blk
+
+
+# --------------------------------------------------------------------------- ensemble
+class ReactorEnsemble:
+    """N independent multi-zone CSTRs resident on one MI355X.
+
+    The whole of ``IntegratedCSTR.step`` (RHS + adaptive Radau + derived + clamps)
+    runs inside one kernel; the host never sees intermediate values.
+    """
+
+    def __init__(self, configs: Union[Sequence[ReactorConfiguration], Dict[str, np.ndarray]],
+                 n_zones: Optional[int] = None, device: int = 0, validate: bool = True):
+        if isinstance(configs, dict):
+            if n_zones is None:
+                raise ValueError("n_zones is required with column input")
+            cols = {k: np.atleast_1d(np.asarray(v)) for k, v in configs.items()}
+            N = max(v.shape[0] for v in cols.values())
+            defaults = ReactorConfiguration()
+            for name in _CFG_FIELDS:
+                if name == "n_zones":
+                    continue
+                v = cols.get(name, np.asarray([getattr(defaults, name)]))
+                cols[name] = np.broadcast_to(v, (N,)).copy()
+            if validate:
+                _validate_columns(cols)
+        else:
+            configs = list(configs)
+            if not configs:
+                raise ValueError("need at least one reactor")
+            nz = {c.n_zones for c in configs}
+            if len(nz) != 1:
+                raise ValueError("all reactors of one ensemble must have the same n_zones")
+            n_zones = nz.pop()
+            if validate:
+                for c in configs:
+                    c.validate()
+            cols = _columns_from_configs(configs)
+            N = len(configs)
+        if n_zones < 2:
+            raise ValueError(f"Need at least 2 zones, got {n_zones}")       # transport.py:88-89
+        self.n_reactors = int(N)
+        self.n_zones = int(n_zones)
+        self.device = int(device)
+        self.columns = cols
+        self.constants = params.derive_constants(cols, self.n_zones)
+        self._h = C.c_void_p()
+        L = _native.lib()
+        _native.check(L.wt_ensemble_create(self.n_reactors, self.n_zones, self.device,
+                                           _native.dptr(np.ascontiguousarray(self.constants)), C.byref(self._h)))
+        shape = (self.n_reactors, self.n_zones)
+        self.set_state(np.broadcast_to(np.asarray(cols["initial_pH"], dtype=np.float64)[:, None], shape),
+                       np.broadcast_to(np.asarray(cols["initial_chlorine"], dtype=np.float64)[:, None], shape),
+                       np.broadcast_to(np.asarray(cols["temperature"], dtype=np.float64)[:, None], shape),
+                       np.zeros(self.n_reactors))
+        self._boundary: Optional[np.ndarray] = None
+
+    # -- lifetime
+    def close(self) -> None:
+        if getattr(self, "_h", None) is not None and self._h:
+            _native.lib().wt_ensemble_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- data movement
+    def set_state(self, pH, chlorine, temperature, time=None) -> None:
+        shape = (self.n_reactors, self.n_zones)
+        a = [np.ascontiguousarray(np.broadcast_to(np.asarray(x, dtype=np.float64), shape)) for x in (pH, chlorine, temperature)]
+        t = None if time is None else np.ascontiguousarray(np.broadcast_to(np.asarray(time, dtype=np.float64), (self.n_reactors,)))
+        _native.check(_native.lib().wt_ensemble_set_state(self._h, _native.dptr(a[0]), _native.dptr(a[1]),
+                                                          _native.dptr(a[2]), _native.dptr(t)))
+
+    def set_boundary(self, boundaries) -> None:
+        blk = boundary_block(boundaries, self.n_reactors)
+        _native.check(_native.lib().wt_ensemble_set_boundary(self._h, _native.dptr(blk)))
+        self._boundary = blk
+
+    def step(self, dt: float, boundaries=None, n_steps: int = 1, fused: bool = True,
+             download: bool = True) -> Optional[EnsembleState]:
+        """Advance every reactor ``n_steps`` outer steps of length ``dt`` [s]."""
+        if boundaries is not None:
+            self.set_boundary(boundaries)
+        if self._boundary is None:
+            raise ValueError("boundary conditions have not been set")
+        try:
+            _native.check(_native.lib().wt_ensemble_step(self._h, float(dt), int(n_steps), 1 if fused else 0))
+        except _native.WtError as e:
+            if e.code == _native.WT_E_ARG:
+                raise ValueError(e.message) from None
+            raise
+        return self.state if download else None
+
+    def synchronize(self) -> None:
+        _native.check(_native.lib().wt_ensemble_synchronize(self._h))
+
+    @property
+    def state(self) -> EnsembleState:
+        N, n = self.n_reactors, self.n_zones
+        pH, Cl, T = np.empty((N, n)), np.empty((N, n)), np.empty((N, n))
+        H, rho, kd = np.empty((N, n)), np.empty((N, n)), np.empty((N, n))
+        t, flow = np.empty(N), np.empty(N)
+        L = _native.lib()
+        _native.check(L.wt_ensemble_get_state(self._h, _native.dptr(pH), _native.dptr(Cl), _native.dptr(T),
+                                              _native.dptr(t), _native.dptr(flow)))
+        _native.check(L.wt_ensemble_get_derived(self._h, _native.dptr(H), _native.dptr(rho), _native.dptr(kd)))
+        return EnsembleState(time=t, pH=pH, chlorine=Cl, temperature=T, flow_rate=flow,
+                             H_concentration=H, density=rho, chlorine_decay_rate=kd, status=self.status())
+
+    def status(self) -> np.ndarray:
+        st = np.zeros(self.n_reactors, dtype=np.uint32)
+        _native.check(_native.lib().wt_ensemble_get_status(self._h, st.ctypes.data_as(C.POINTER(C.c_uint32))))
+        return st
+
+    def clear_status(self) -> None:
+        _native.check(_native.lib().wt_ensemble_clear_status(self._h))
+
+    def solver_stats(self) -> np.ndarray:
+        """(N, 5) int32: nfev, njev, nlu, accepted, rejected of the last outer step."""
+        arr = np.zeros((self.n_reactors, 5), dtype=np.int32)
+        _native.check(_native.lib().wt_ensemble_get_stats(self._h, arr.ctypes.data_as(C.POINTER(_native.SolverStats))))
+        return arr
+
+    def derivatives(self, pH, chlorine, temperature):
+        """Batched ``IntegratedCSTR.derivatives`` at the given states; returns (dpH, dCl, dT, flags)."""
+        shape = (self.n_reactors, self.n_zones)
+        a = [np.ascontiguousarray(np.broadcast_to(np.asarray(x, dtype=np.float64), shape)) for x in (pH, chlorine, temperature)]
+        out = [np.empty(shape) for _ in range(3)]
+        fl = np.zeros(self.n_reactors, dtype=np.uint32)
+        _native.check(_native.lib().wt_ensemble_rhs(self._h, *[_native.dptr(x) for x in a], *[_native.dptr(x) for x in out],
+                                                   fl.ctypes.data_as(C.POINTER(C.c_uint32))))
+        return out[0], out[1], out[2], fl
+
+    def export_state_device(self, device_ptr: int) -> None:
+        """Async device-to-device copy of [pH, Cl, T] (3, N, n) into caller device memory."""
+        _native.check(_native.lib().wt_ensemble_export_state_device(self._h, C.c_void_p(device_ptr)))
+
+    def set_stream(self, hip_stream: int) -> None:
+        _native.check(_native.lib().wt_ensemble_set_stream(self._h, C.c_void_p(hip_stream)))
+
+    def timer_start(self) -> None:
+        _native.check(_native.lib().wt_ensemble_timer_start(self._h))
+
+    def timer_stop(self) -> float:
+        ms = C.c_float(0.0)
+        _native.check(_native.lib().wt_ensemble_timer_stop(self._h, C.byref(ms)))
+        return float(ms.value)
+
+
+def _validate_columns(cols: Dict[str, np.ndarray]) -> None:
+    """Vectorised ReactorConfiguration.validate (reactor.py:91-110)."""
+    calc = np.pi * (cols["diameter"] / 2) ** 2 * cols["height"] * 1000
+    err = np.abs(calc - cols["volume"]) / cols["volume"]
+    if np.any(err > 0.01):
+        r = int(np.argmax(err > 0.01))
+        raise ValueError(f"Volume mismatch: specified {cols['volume'][r]}L, calculated {calc[r]:.1f}L "
+                         f"from geometry. Error: {err[r]*100:.1f}%")
+    assert np.all((0 < cols["volume"]) & (cols["volume"] < 1e6)), "Volume out of range"
+    assert np.all((0 <= cols["flow_rate"]) & (cols["flow_rate"] < 1e5)), "Flow rate out of range (use 0 for batch mode)"
+    assert np.all((0 <= cols["initial_pH"]) & (cols["initial_pH"] <= 14)), "pH out of range"
+    assert np.all((0 <= cols["initial_chlorine"]) & (cols["initial_chlorine"] <= 10)), "Chlorine out of range"
+    assert np.all((0 <= cols["temperature"]) & (cols["temperature"] <= 40)), "Temperature out of typical range"
+
+
+# --------------------------------------------------------------------------- single-reactor drop-in
+class IntegratedCSTR:
+    """Drop-in for the reference class of the same name (reactor.py:189-611),
+    backed by a one-reactor ensemble on the GPU."""
+
+    def __init__(self, config: ReactorConfiguration, device: int = 0):
+        config.validate()
+        self.config = config
+        self._ens = ReactorEnsemble([config], device=device, validate=False)
+        n = config.n_zones
+        c = self._ens.constants[:, 0]
+        self.transport = SimpleNamespace(
+            residence_time=params.residence_time_min(config.volume, config.flow_rate),
+            superficial_velocity=float(c[params.P_USUP]),
+            K_exchange_per_s=float(c[params.P_KEX]),
+            is_batch_mode=config.flow_rate == 0.0)
+        self.state = ReactorState(
+            pH=np.full(n, config.initial_pH),
+            chlorine=np.full(n, config.initial_chlorine),
+            temperature=np.full(n, config.temperature),
+            flow_rate=config.flow_rate)
+        # same log line as reactor.py:224-227 (and, as there, a TypeError when
+        # flow_rate == 0 because residence_time is None)
+        logger.info(f"Reactor initialized: {config.n_zones} zones, "
+                    f"V={config.volume}L, τ={self.transport.residence_time:.1f}min")
+
+    def derivatives(self, t: float, y: np.ndarray, boundary: BoundaryConditions) -> np.ndarray:
+        n = self.config.n_zones
+        y = np.asarray(y, dtype=np.float64)
+        self._ens.set_boundary(boundary)
+        dpH, dCl, dT, fl = self._ens.derivatives(y[None, 0:n], y[None, n:2 * n], y[None, 2 * n:3 * n])
+        if fl[0] & ST_T_RANGE:
+            T = y[2 * n:3 * n]
+            bad = T[(T < 0) | (T > 100)]
+            raise ValueError(_T_RANGE_TEXT.format(value=bad[0] if bad.size else "nan"))
+        return np.concatenate([dpH[0], dCl[0], dT[0]])
+
+    def step(self, dt: float, boundary: BoundaryConditions) -> ReactorState:
+        """Advance by ``dt`` seconds under ``boundary`` (reactor.py:450-509)."""
+        ens = self._ens
+        s = self.state
+        # honour host-side edits of self.state between steps (reactor.py:467-469)
+        ens.set_state(np.asarray(s.pH, dtype=np.float64)[None, :], np.asarray(s.chlorine, dtype=np.float64)[None, :],
+                      np.asarray(s.temperature, dtype=np.float64)[None, :], np.array([s.time], dtype=np.float64))
+        es = ens.step(dt, boundary, n_steps=1)
+        flags = int(es.status[0])
+        if flags & ST_T_RANGE:
+            raise ValueError(_T_RANGE_TEXT.format(value="<zone value>"))
+        if flags & ST_SOLVER_FAILED:
+            logger.warning(_SOLVER_FAILED_TEXT)
+        pre = None
+        s.pH, s.chlorine, s.temperature = es.pH[0].copy(), es.chlorine[0].copy(), es.temperature[0].copy()
+        s.time = float(es.time[0])
+        s.flow_rate = float(es.flow_rate[0])
+        s.H_concentration = es.H_concentration[0].copy()
+        s.density = es.density[0].copy()
+        if flags & ST_T_RANGE_POST:
+            raise ValueError(_T_RANGE_TEXT.format(value="<zone value>"))
+        s.chlorine_decay_rate = es.chlorine_decay_rate[0].copy()
+        if flags & ST_CLAMP_PH:
+            logger.error("pH out of bounds: clipped to [0, 14]")
+        if flags & ST_CLAMP_CL:
+            logger.warning("Negative chlorine detected: clipped to 0")
+        if flags & ST_CLAMP_T:
+            logger.error("Temperature out of bounds: clipped to [0, 100]")
+        return s
+
+    def get_state_at_location(self, zone_idx: int, parameter: str) -> float:
+        if zone_idx < 0 or zone_idx >= self.config.n_zones:
+            raise ValueError(f"Zone index {zone_idx} out of range [0, {self.config.n_zones-1}]")
+        table = {"pH": self.state.pH, "chlorine": self.state.chlorine,
+                 "temperature": self.state.temperature, "density": self.state.density}
+        if parameter not in table:
+            raise ValueError(f"Unknown parameter: {parameter}")
+        return table[parameter][zone_idx]
+
+    def validate_conservation(self) -> Dict[str, float]:
+        """Mass / charge / energy inventory (reactor.py:570-611)."""
+        zone_volume = self.config.volume / self.config.n_zones
+        total_chlorine_mg = np.sum(self.state.chlorine) * zone_volume
+        total_H_mol = np.sum(self.state.H_concentration) * zone_volume / 1000
+        Kw = float(params.water_ionization_constant(np.array([self.state.temperature[0]]))[0])
+        total_OH_mol = np.sum(Kw / self.state.H_concentration) * zone_volume / 1000
+        V_m3 = self.config.volume / 1000
+        thermal_energy_kJ = 998.2 * 4184 * V_m3 * np.mean(self.state.temperature - 20.0) / 1000
+        return {"total_chlorine_mg": total_chlorine_mg, "total_H_mol": total_H_mol,
+                "total_OH_mol": total_OH_mol, "charge_balance_mol": total_H_mol - total_OH_mol,
+                "thermal_energy_kJ": thermal_energy_kJ, "zones": self.config.n_zones,
+                "timestamp": self.state.time}
+
+
+PhysicsEngine = IntegratedCSTR  # the name BASELINE.json uses for this API

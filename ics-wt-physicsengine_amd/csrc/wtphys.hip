@@ -1,0 +1,422 @@
+// wtphys.hip -- host side of libwtphys.so: the C ABI declared in include/wtphys.h.
+// Owns device memory behind an opaque handle, uploads the SoA constant / boundary
+// blocks, launches the gfx950 kernels of wt_device.hpp on the handle's stream.
+#include "wt_device.hpp"
+#include "../../include/wtphys.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string &msg)
+{
+    g_err = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                       \
+    do {                                                                                    \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess)                                                               \
+            return fail(WT_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));       \
+    } while (0)
+
+// radau.py:11-40 and common.py:248-253, evaluated with the same expressions
+wt::RadauConsts make_consts()
+{
+    wt::RadauConsts c;
+    const double S6 = std::pow(6.0, 0.5);
+    c.C[0] = (4 - S6) / 10; c.C[1] = (4 + S6) / 10; c.C[2] = 1.0;
+    c.E[0] = (-13 - 7 * S6) / 3; c.E[1] = (-13 + 7 * S6) / 3; c.E[2] = -1.0 / 3;
+    c.MU_REAL = 3 + std::pow(3.0, 2.0 / 3) - std::pow(3.0, 1.0 / 3);
+    c.MU_CR = 3 + 0.5 * (std::pow(3.0, 1.0 / 3) - std::pow(3.0, 2.0 / 3));
+    c.MU_CI = -0.5 * (std::pow(3.0, 5.0 / 6) + std::pow(3.0, 7.0 / 6));
+    const double T[3][3] = {{0.09443876248897524, -0.14125529502095421, 0.03002919410514742},
+                            {0.25021312296533332, 0.20412935229379994, -0.38294211275726192},
+                            {1, 1, 0}};
+    const double TI[3][3] = {{4.17871859155190428, 0.32768282076106237, 0.52337644549944951},
+                             {-4.17871859155190428, -0.32768282076106237, 0.47662355450055044},
+                             {0.50287263494578682, -2.57192694985560522, 0.59603920482822492}};
+    const double P[3][3] = {{13.0 / 3 + 7 * S6 / 3, -23.0 / 3 - 22 * S6 / 3, 10.0 / 3 + 5 * S6},
+                            {13.0 / 3 - 7 * S6 / 3, -23.0 / 3 + 22 * S6 / 3, 10.0 / 3 - 5 * S6},
+                            {1.0 / 3, -8.0 / 3, 10.0 / 3}};
+    std::memcpy(c.T, T, sizeof T); std::memcpy(c.TI, TI, sizeof TI); std::memcpy(c.P, P, sizeof P);
+    const double EPS = 2.220446049250313e-16;
+    c.NJ_REJECT = std::pow(EPS, 0.875); c.NJ_SMALL = std::pow(EPS, 0.75); c.NJ_BIG = std::pow(EPS, 0.25);
+    c.NJ_MINF = 1e3 * EPS; c.NJ_F0 = std::pow(EPS, 0.5);
+    c.newton_tol = std::fmax(10 * EPS / wt::RTOL, std::fmin(0.03, std::pow(wt::RTOL, 0.5)));
+    return c;
+}
+
+int levels_for(int n)
+{
+    int l = 0;
+    while ((1 << l) < n) ++l;
+    return l < 1 ? 1 : l;
+}
+
+} // namespace
+
+struct wt_ensemble {
+    int64_t N = 0;
+    int n = 0, R = 0, device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    double *par = nullptr, *bc = nullptr;
+    double *pH = nullptr, *Cl = nullptr, *T = nullptr, *time = nullptr, *flow = nullptr;
+    double *dH = nullptr, *dRho = nullptr, *dK = nullptr;
+    uint32_t *status = nullptr;
+    int32_t *stats = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool have_bc = false, have_state = false;
+    wt::RadauConsts rc;
+};
+
+namespace {
+
+wt::StepArgs make_args(const wt_ensemble *h, double dt, int n_steps)
+{
+    wt::StepArgs a;
+    a.N = h->N; a.n = h->n; a.R = h->R;
+    a.par = h->par; a.bc = h->bc;
+    a.pH = h->pH; a.Cl = h->Cl; a.T = h->T; a.time = h->time; a.flow = h->flow;
+    a.dH = h->dH; a.dRho = h->dRho; a.dK = h->dK;
+    a.status = h->status; a.stats = h->stats;
+    a.dt = dt; a.n_steps = n_steps; a.rc = h->rc;
+    return a;
+}
+
+void launch_step(const wt_ensemble *h, const wt::StepArgs &a)
+{
+    const unsigned grid = (unsigned)((h->N + h->R - 1) / h->R);
+    switch (levels_for(h->n)) {
+    case 1: hipLaunchKernelGGL(wt::step_kernel<1>, dim3(grid), dim3(64), 0, h->stream, a); break;
+    case 2: hipLaunchKernelGGL(wt::step_kernel<2>, dim3(grid), dim3(64), 0, h->stream, a); break;
+    case 3: hipLaunchKernelGGL(wt::step_kernel<3>, dim3(grid), dim3(64), 0, h->stream, a); break;
+    case 4: hipLaunchKernelGGL(wt::step_kernel<4>, dim3(grid), dim3(64), 0, h->stream, a); break;
+    case 5: hipLaunchKernelGGL(wt::step_kernel<5>, dim3(grid), dim3(64), 0, h->stream, a); break;
+    default: hipLaunchKernelGGL(wt::step_kernel<6>, dim3(grid), dim3(64), 0, h->stream, a); break;
+    }
+}
+
+} // namespace
+
+extern "C" {
+
+int wt_abi_version(void) { return WT_ABI_VERSION; }
+const char *wt_last_error(void) { return g_err.c_str(); }
+
+int wt_device_count(int *count)
+{
+    if (!count) return fail(WT_E_ARG, "count is NULL");
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) { *count = 0; return fail(WT_E_NOGPU, hipGetErrorString(e)); }
+    *count = c;
+    return WT_OK;
+}
+
+int wt_ensemble_create(int64_t n_reactors, int n_zones, int device, const double *par, wt_ensemble **out)
+{
+    if (!out || !par) return fail(WT_E_ARG, "NULL argument");
+    *out = nullptr;
+    if (n_reactors <= 0) return fail(WT_E_ARG, "n_reactors must be positive");
+    if (n_zones < 2 || n_zones > WT_MAX_ZONES)
+        return fail(WT_E_ARG, "Need at least 2 zones and at most 64, got " + std::to_string(n_zones));
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(WT_E_NOGPU, "no HIP device available: libwtphys has no CPU path");
+    if (device < 0 || device >= ndev) return fail(WT_E_ARG, "bad device index");
+    HIP_TRY(hipSetDevice(device));
+    wt_ensemble *h = new wt_ensemble();
+    h->N = n_reactors; h->n = n_zones; h->R = 64 / n_zones; h->device = device;
+    h->rc = make_consts();
+    const size_t N = (size_t)n_reactors, nz = (size_t)n_zones;
+    auto cleanup = [&]() { wt_ensemble_destroy(h); };
+#define ALLOC(ptr, bytes)                                                                   \
+    do {                                                                                    \
+        hipError_t e_ = hipMalloc((void **)&(ptr), (bytes));                                \
+        if (e_ != hipSuccess) { cleanup(); return fail(WT_E_HIP, std::string("hipMalloc: ") + hipGetErrorString(e_)); } \
+    } while (0)
+    ALLOC(h->par, sizeof(double) * WT_NP * N);
+    ALLOC(h->bc, sizeof(double) * WT_NB * N);
+    ALLOC(h->pH, sizeof(double) * N * nz);
+    ALLOC(h->Cl, sizeof(double) * N * nz);
+    ALLOC(h->T, sizeof(double) * N * nz);
+    ALLOC(h->dH, sizeof(double) * N * nz);
+    ALLOC(h->dRho, sizeof(double) * N * nz);
+    ALLOC(h->dK, sizeof(double) * N * nz);
+    ALLOC(h->time, sizeof(double) * N);
+    ALLOC(h->flow, sizeof(double) * N);
+    ALLOC(h->status, sizeof(uint32_t) * N);
+    ALLOC(h->stats, sizeof(int32_t) * 5 * N);
+#undef ALLOC
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { cleanup(); return fail(WT_E_HIP, "hipStreamCreate failed"); }
+    h->own_stream = true;
+    if (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) { cleanup(); return fail(WT_E_HIP, "hipEventCreate failed"); }
+    hipError_t e = hipMemcpyAsync(h->par, par, sizeof(double) * WT_NP * N, hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(h->status, 0, sizeof(uint32_t) * N, h->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(h->stats, 0, sizeof(int32_t) * 5 * N, h->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(h->time, 0, sizeof(double) * N, h->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(h->flow, 0, sizeof(double) * N, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e != hipSuccess) { cleanup(); return fail(WT_E_HIP, std::string("upload: ") + hipGetErrorString(e)); }
+    *out = h;
+    return WT_OK;
+}
+
+int wt_ensemble_destroy(wt_ensemble *h)
+{
+    if (!h) return WT_OK;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    void *ptrs[] = {h->par, h->bc, h->pH, h->Cl, h->T, h->time, h->flow, h->dH, h->dRho, h->dK, h->status, h->stats};
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return WT_OK;
+}
+
+int wt_ensemble_set_stream(wt_ensemble *h, void *hip_stream)
+{
+    if (!h) return fail(WT_E_ARG, "NULL handle");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+    h->stream = (hipStream_t)hip_stream;
+    h->own_stream = false;
+    return WT_OK;
+}
+
+int wt_ensemble_set_state(wt_ensemble *h, const double *pH, const double *Cl, const double *T, const double *time)
+{
+    if (!h || !pH || !Cl || !T) return fail(WT_E_ARG, "NULL argument");
+    HIP_TRY(hipSetDevice(h->device));
+    const size_t cnt = (size_t)h->N * h->n;
+    HIP_TRY(hipMemcpyAsync(h->pH, pH, sizeof(double) * cnt, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->Cl, Cl, sizeof(double) * cnt, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->T, T, sizeof(double) * cnt, hipMemcpyHostToDevice, h->stream));
+    if (time) HIP_TRY(hipMemcpyAsync(h->time, time, sizeof(double) * h->N, hipMemcpyHostToDevice, h->stream));
+    // ReactorState.update_derived placeholders (reactor.py:137-147)
+    std::vector<double> tmp(cnt);
+    for (size_t i = 0; i < cnt; ++i) tmp[i] = std::pow(10.0, -pH[i]);
+    HIP_TRY(hipMemcpyAsync(h->dH, tmp.data(), sizeof(double) * cnt, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    std::fill(tmp.begin(), tmp.end(), 998.2);
+    HIP_TRY(hipMemcpyAsync(h->dRho, tmp.data(), sizeof(double) * cnt, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    std::fill(tmp.begin(), tmp.end(), 0.0001);
+    HIP_TRY(hipMemcpyAsync(h->dK, tmp.data(), sizeof(double) * cnt, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemsetAsync(h->status, 0, sizeof(uint32_t) * h->N, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    h->have_state = true;
+    return WT_OK;
+}
+
+int wt_ensemble_set_boundary(wt_ensemble *h, const double *bc)
+{
+    if (!h || !bc) return fail(WT_E_ARG, "NULL argument");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipMemcpyAsync(h->bc, bc, sizeof(double) * WT_NB * h->N, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    h->have_bc = true;
+    return WT_OK;
+}
+
+int wt_ensemble_step(wt_ensemble *h, double dt, int n_steps, int fused)
+{
+    if (!h) return fail(WT_E_ARG, "NULL handle");
+    if (!h->have_state || !h->have_bc) return fail(WT_E_STATE, "set_state and set_boundary must precede step");
+    if (!(dt > 0)) return fail(WT_E_ARG, "`max_step` must be positive."); // scipy validate_max_step (reactor.py:480)
+    if (n_steps < 0) return fail(WT_E_ARG, "n_steps must be >= 0");
+    if (n_steps == 0) return WT_OK;
+    HIP_TRY(hipSetDevice(h->device));
+    if (fused) {
+        launch_step(h, make_args(h, dt, n_steps));
+    } else {
+        const wt::StepArgs a = make_args(h, dt, 1);
+        for (int s = 0; s < n_steps; ++s) launch_step(h, a);
+    }
+    HIP_TRY(hipGetLastError());
+    return WT_OK;
+}
+
+int wt_ensemble_synchronize(wt_ensemble *h)
+{
+    if (!h) return fail(WT_E_ARG, "NULL handle");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return WT_OK;
+}
+
+static int d2h(wt_ensemble *h, void *dst, const void *src, size_t bytes)
+{
+    if (!dst) return WT_OK;
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, h->stream));
+    return WT_OK;
+}
+
+int wt_ensemble_get_state(wt_ensemble *h, double *pH, double *Cl, double *T, double *time, double *flow)
+{
+    if (!h) return fail(WT_E_ARG, "NULL handle");
+    HIP_TRY(hipSetDevice(h->device));
+    const size_t b = sizeof(double) * (size_t)h->N * h->n;
+    int rc;
+    if ((rc = d2h(h, pH, h->pH, b))) return rc;
+    if ((rc = d2h(h, Cl, h->Cl, b))) return rc;
+    if ((rc = d2h(h, T, h->T, b))) return rc;
+    if ((rc = d2h(h, time, h->time, sizeof(double) * h->N))) return rc;
+    if ((rc = d2h(h, flow, h->flow, sizeof(double) * h->N))) return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return WT_OK;
+}
+
+int wt_ensemble_get_derived(wt_ensemble *h, double *H, double *rho, double *kdecay)
+{
+    if (!h) return fail(WT_E_ARG, "NULL handle");
+    HIP_TRY(hipSetDevice(h->device));
+    const size_t b = sizeof(double) * (size_t)h->N * h->n;
+    int rc;
+    if ((rc = d2h(h, H, h->dH, b))) return rc;
+    if ((rc = d2h(h, rho, h->dRho, b))) return rc;
+    if ((rc = d2h(h, kdecay, h->dK, b))) return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return WT_OK;
+}
+
+int wt_ensemble_get_status(wt_ensemble *h, uint32_t *flags)
+{
+    if (!h || !flags) return fail(WT_E_ARG, "NULL argument");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipMemcpyAsync(flags, h->status, sizeof(uint32_t) * h->N, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return WT_OK;
+}
+
+int wt_ensemble_clear_status(wt_ensemble *h)
+{
+    if (!h) return fail(WT_E_ARG, "NULL handle");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipMemsetAsync(h->status, 0, sizeof(uint32_t) * h->N, h->stream));
+    return WT_OK;
+}
+
+int wt_ensemble_get_stats(wt_ensemble *h, wt_solver_stats *stats)
+{
+    if (!h || !stats) return fail(WT_E_ARG, "NULL argument");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipMemcpyAsync(stats, h->stats, sizeof(int32_t) * 5 * h->N, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return WT_OK;
+}
+
+int wt_ensemble_rhs(wt_ensemble *h, const double *pH, const double *Cl, const double *T,
+                    double *dpH, double *dCl, double *dT, uint32_t *flags)
+{
+    if (!h || !pH || !Cl || !T || !dpH || !dCl || !dT || !flags) return fail(WT_E_ARG, "NULL argument");
+    if (!h->have_bc) return fail(WT_E_STATE, "set_boundary must precede rhs");
+    HIP_TRY(hipSetDevice(h->device));
+    const size_t cnt = (size_t)h->N * h->n, b = sizeof(double) * cnt;
+    double *buf = nullptr; uint32_t *fl = nullptr;
+    HIP_TRY(hipMalloc((void **)&buf, 6 * b));
+    if (hipMalloc((void **)&fl, sizeof(uint32_t) * h->N) != hipSuccess) { (void)hipFree(buf); return fail(WT_E_HIP, "hipMalloc failed"); }
+    hipError_t e = hipMemcpyAsync(buf, pH, b, hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(buf + cnt, Cl, b, hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(buf + 2 * cnt, T, b, hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) {
+        wt::RhsArgs a;
+        a.N = h->N; a.n = h->n; a.R = h->R; a.par = h->par; a.bc = h->bc;
+        a.pH = buf; a.Cl = buf + cnt; a.T = buf + 2 * cnt;
+        a.dpH = buf + 3 * cnt; a.dCl = buf + 4 * cnt; a.dT = buf + 5 * cnt; a.flags = fl;
+        const unsigned grid = (unsigned)((h->N + h->R - 1) / h->R);
+        hipLaunchKernelGGL(wt::rhs_kernel, dim3(grid), dim3(64), 0, h->stream, a);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(dpH, buf + 3 * cnt, b, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(dCl, buf + 4 * cnt, b, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(dT, buf + 5 * cnt, b, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(flags, fl, sizeof(uint32_t) * h->N, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    (void)hipFree(buf); (void)hipFree(fl);
+    if (e != hipSuccess) return fail(WT_E_HIP, std::string("rhs: ") + hipGetErrorString(e));
+    return WT_OK;
+}
+
+int wt_ensemble_export_state_device(wt_ensemble *h, void *dst_device)
+{
+    if (!h || !dst_device) return fail(WT_E_ARG, "NULL argument");
+    HIP_TRY(hipSetDevice(h->device));
+    const size_t cnt = (size_t)h->N * h->n, b = sizeof(double) * cnt;
+    double *d = (double *)dst_device;
+    HIP_TRY(hipMemcpyAsync(d, h->pH, b, hipMemcpyDeviceToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(d + cnt, h->Cl, b, hipMemcpyDeviceToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(d + 2 * cnt, h->T, b, hipMemcpyDeviceToDevice, h->stream));
+    return WT_OK;
+}
+
+int wt_ensemble_timer_start(wt_ensemble *h)
+{
+    if (!h) return fail(WT_E_ARG, "NULL handle");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipEventRecord(h->ev0, h->stream));
+    return WT_OK;
+}
+
+int wt_ensemble_timer_stop(wt_ensemble *h, float *elapsed_ms)
+{
+    if (!h || !elapsed_ms) return fail(WT_E_ARG, "NULL argument");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipEventRecord(h->ev1, h->stream));
+    HIP_TRY(hipEventSynchronize(h->ev1));
+    HIP_TRY(hipEventElapsedTime(elapsed_ms, h->ev0, h->ev1));
+    return WT_OK;
+}
+
+int64_t wt_ensemble_size(const wt_ensemble *h) { return h ? h->N : 0; }
+int wt_ensemble_zones(const wt_ensemble *h) { return h ? h->n : 0; }
+
+int wt_ph_solve(int device, int64_t n, const double *Kw, const double *Ka1, const double *Ka2,
+                const double *CT_mol, const double *alk_mgL, const double *guess,
+                double tol, int max_iter, double *pH_out, int32_t *iters, int32_t *rc)
+{
+    if (n < 0 || !Kw || !Ka1 || !Ka2 || !CT_mol || !alk_mgL || !guess || !pH_out || !iters || !rc)
+        return fail(WT_E_ARG, "NULL argument");
+    if (n == 0) return WT_OK;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(WT_E_NOGPU, "no HIP device available: libwtphys has no CPU path");
+    if (device < 0 || device >= ndev) return fail(WT_E_ARG, "bad device index");
+    HIP_TRY(hipSetDevice(device));
+    const size_t b = sizeof(double) * (size_t)n;
+    double *buf = nullptr; int32_t *ib = nullptr;
+    HIP_TRY(hipMalloc((void **)&buf, 7 * b));
+    if (hipMalloc((void **)&ib, 2 * sizeof(int32_t) * (size_t)n) != hipSuccess) { (void)hipFree(buf); return fail(WT_E_HIP, "hipMalloc failed"); }
+    const double *src[6] = {Kw, Ka1, Ka2, CT_mol, alk_mgL, guess};
+    hipError_t e = hipSuccess;
+    for (int i = 0; i < 6 && e == hipSuccess; ++i) e = hipMemcpy(buf + (size_t)i * n, src[i], b, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        wt::PhArgs a;
+        a.n = n; a.Kw = buf; a.Ka1 = buf + n; a.Ka2 = buf + 2 * n; a.CT = buf + 3 * n; a.alk = buf + 4 * n;
+        a.guess = buf + 5 * n; a.tol = tol; a.max_iter = max_iter; a.pH = buf + 6 * n; a.iters = ib; a.rc = ib + n;
+        const unsigned grid = (unsigned)((n + 255) / 256);
+        hipLaunchKernelGGL(wt::ph_solve_kernel, dim3(grid), dim3(256), 0, 0, a);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(pH_out, buf + 6 * (size_t)n, b, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(iters, ib, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(rc, ib + n, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost);
+    (void)hipFree(buf); (void)hipFree(ib);
+    if (e != hipSuccess) return fail(WT_E_HIP, std::string("ph_solve: ") + hipGetErrorString(e));
+    return WT_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,141 @@
+/*
+ * wtphys.h -- C ABI of libwtphys.so: the MI355X (gfx950) implementation of the
+ * multi-zone CSTR physics step of wt_simulator.core, batched over an ensemble
+ * of independent reactors.
+ *
+ * The reference has no FFI: its boundary for this path is the Python class
+ * API  IntegratedCSTR(config).step(dt, boundary) -> ReactorState
+ * (/root/reference/src/wt_simulator/core/reactor.py:203, :450-509).  Each entry
+ * point below names the reference interface it stands in for.  All functions
+ * return 0 on success or a WT_E_* code; wt_last_error() gives the text.  No
+ * exception or torch type crosses this boundary; pointers are plain host (or,
+ * where stated, device) pointers.
+ *
+ * Data layout (all fp64):
+ *   state   pH, Cl, T : [N][n]   reactor-major, zone fastest  (= numpy (N, n))
+ *   par     [WT_NP][N]           per-reactor constants, SoA   (see WT_P_*)
+ *   bc      [WT_NB][N]           BoundaryConditions columns, SoA (see WT_B_*)
+ * One handle = one device, one HIP stream, one caller thread (not re-entrant).
+ */
+#ifndef WTPHYS_H
+#define WTPHYS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WT_ABI_VERSION 1
+#define WT_MAX_ZONES 64 /* one reactor's zones live in one 64-lane wavefront */
+
+/* rows of the per-reactor constant block (values as the reference's __init__
+ * computes them: reactor.py:229-270, chemistry.py:116-132, transport.py:202-290) */
+enum {
+    WT_P_VOLUME = 0, WT_P_HEIGHT = 1, WT_P_DIAMETER = 2,
+    WT_P_KW = 3, WT_P_KA1 = 4, WT_P_KA2 = 5, WT_P_KA_HOCL = 6, WT_P_CT_MOL = 7,
+    WT_P_KEX = 8, WT_P_USUP = 9, WT_P_STRAT = 10, WT_P_RI_CRIT = 11, WT_P_SUPP = 12,
+    WT_NP = 16
+};
+
+/* rows of the boundary block = BoundaryConditions fields, reactor.py:169-186 */
+enum {
+    WT_B_Q_IN = 0, WT_B_PH_IN = 1, WT_B_CL_IN = 2, WT_B_T_IN = 3,
+    WT_B_Q_ACID = 4, WT_B_C_ACID = 5, WT_B_Q_CL = 6, WT_B_C_CL = 7,
+    WT_B_T_AMB = 8, WT_B_U = 9,
+    WT_NB = 10
+};
+
+/* per-reactor status bits (OR-accumulated until cleared) */
+enum {
+    WT_ST_T_RANGE = 1,        /* a zone temperature left [0,100] C inside the solve: the reference
+                                 raises ValueError (thermodynamics.py:146-157); state is NOT advanced
+                                 and the reactor stays frozen until the host rewrites its state */
+    WT_ST_SOLVER_FAILED = 2,  /* Radau "step size too small" -> reactor.py:486-487 warning; state is
+                                 still overwritten with the last accepted y, as the reference does */
+    WT_ST_CLAMP_PH = 4,       /* reactor.py:529-531 */
+    WT_ST_CLAMP_CL = 8,       /* reactor.py:534-536 */
+    WT_ST_CLAMP_T = 16,       /* reactor.py:539-541 */
+    WT_ST_T_RANGE_POST = 32,  /* ValueError out of _update_derived_state (reactor.py:522-524):
+                                 state/time/H/density were updated, decay rate and clamps were not */
+    WT_ST_NONFINITE = 64
+};
+
+enum {
+    WT_OK = 0, WT_E_ARG = 1, WT_E_HIP = 2, WT_E_NOGPU = 3, WT_E_STATE = 4
+};
+
+typedef struct wt_ensemble wt_ensemble;
+
+/* per-reactor solver counters of the LAST outer step (scipy's nfev/njev/nlu,
+ * accepted and rejected internal steps); used by the parity tests to check the
+ * decision sequence against the oracle. */
+typedef struct { int32_t nfev, njev, nlu, nsteps, nrej; } wt_solver_stats;
+
+int wt_abi_version(void);
+const char *wt_last_error(void);
+int wt_device_count(int *count);
+
+/* IntegratedCSTR.__init__ (reactor.py:203-227) for N reactors with n zones each
+ * on HIP device `device`.  `par` is host memory, [WT_NP][N]. */
+int wt_ensemble_create(int64_t n_reactors, int n_zones, int device, const double *par,
+                       wt_ensemble **out);
+int wt_ensemble_destroy(wt_ensemble *h);
+
+/* overwrite reactor.state.{pH,chlorine,temperature,time} (reactor.py:217-222,
+ * and the documented "callers may edit state between steps" path :467-469).
+ * Host arrays [N][n]; `time` [N] may be NULL (keeps current).  Clears status. */
+int wt_ensemble_set_state(wt_ensemble *h, const double *pH, const double *Cl, const double *T,
+                          const double *time);
+/* BoundaryConditions for every reactor (reactor.py:150-186), host [WT_NB][N]. */
+int wt_ensemble_set_boundary(wt_ensemble *h, const double *bc);
+
+/* IntegratedCSTR.step(dt, boundary) n_steps times (reactor.py:450-509), boundary
+ * held constant; asynchronous on the handle's stream.  fused != 0 keeps the
+ * state in registers across the n_steps outer steps of one launch; fused == 0
+ * launches one kernel per outer step. */
+int wt_ensemble_step(wt_ensemble *h, double dt, int n_steps, int fused);
+int wt_ensemble_synchronize(wt_ensemble *h);
+
+/* ReactorState read-back (reactor.py:113-147).  Any pointer may be NULL.
+ * pH/Cl/T [N][n]; time, flow [N]. Synchronises the stream. */
+int wt_ensemble_get_state(wt_ensemble *h, double *pH, double *Cl, double *T, double *time,
+                          double *flow);
+/* H_concentration, density, chlorine_decay_rate (reactor.py:511-524), [N][n] each. */
+int wt_ensemble_get_derived(wt_ensemble *h, double *H, double *rho, double *kdecay);
+int wt_ensemble_get_status(wt_ensemble *h, uint32_t *flags /* [N] */);
+int wt_ensemble_clear_status(wt_ensemble *h);
+int wt_ensemble_get_stats(wt_ensemble *h, wt_solver_stats *stats /* [N] */);
+
+/* IntegratedCSTR.derivatives(t, y, boundary) (reactor.py:272-448) for every
+ * reactor at caller-supplied states (host [N][n]); uses the handle's constants
+ * and boundary.  flags[N] gets WT_ST_T_RANGE where the reference would raise. */
+int wt_ensemble_rhs(wt_ensemble *h, const double *pH, const double *Cl, const double *T,
+                    double *dpH, double *dCl, double *dT, uint32_t *flags);
+
+/* Device-side access for zero-copy consumers (RCCL gather, fused sensors):
+ * copies the current state into caller DEVICE memory laid out [3][N][n]
+ * (pH, Cl, T), asynchronously on the handle's stream. */
+int wt_ensemble_export_state_device(wt_ensemble *h, void *dst_device);
+/* Use a caller-owned hipStream_t (e.g. torch's current stream) for all work. */
+int wt_ensemble_set_stream(wt_ensemble *h, void *hip_stream);
+
+/* HIP-event bracketing on the handle's stream, for benchmarks. */
+int wt_ensemble_timer_start(wt_ensemble *h);
+int wt_ensemble_timer_stop(wt_ensemble *h, float *elapsed_ms /* synchronises */);
+
+int64_t wt_ensemble_size(const wt_ensemble *h);
+int wt_ensemble_zones(const wt_ensemble *h);
+
+/* AqueousChemistry.calculate_pH (chemistry.py:271-330) batched: Newton-Raphson
+ * on the charge balance, one system per element.  Host arrays of length n.
+ * rc[i]: 0 converged, 1 "derivative too small" (RuntimeError), 2 no convergence. */
+int wt_ph_solve(int device, int64_t n, const double *Kw, const double *Ka1, const double *Ka2,
+                const double *CT_mol, const double *alk_mgL, const double *guess,
+                double tol, int max_iter, double *pH_out, int32_t *iters, int32_t *rc);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WTPHYS_H */
