@@ -5,8 +5,9 @@ from .reactor import (BoundaryConditions, EnsembleState, IntegratedCSTR, Physics
                       ReactorConfiguration, ReactorEnsemble, ReactorState, boundary_block)
 from .chemistry import AqueousChemistry, BufferSystem, solve_pH
 from .synthetic import make_ensemble
-from . import params
+from . import params, sharding
+from .sharding import gather_state, shard_bounds
 
 __all__ = ["BoundaryConditions", "EnsembleState", "IntegratedCSTR", "PhysicsEngine", "ReactorConfiguration",
            "ReactorEnsemble", "ReactorState", "boundary_block", "AqueousChemistry", "BufferSystem",
-           "solve_pH", "make_ensemble", "params"]
+           "solve_pH", "make_ensemble", "params", "sharding", "gather_state", "shard_bounds"]

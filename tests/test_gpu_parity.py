@@ -1,0 +1,297 @@
+"""Parity of the HIP path (through the C ABI) with the CPU oracle and with the
+reference's golden vectors.  Tolerance: per-zone pH / Cl / T within 1e-6
+relative of the reference CPU step (BASELINE.json north_star); observed
+agreement is orders of magnitude tighter and is asserted at 1e-7 for the
+golden trajectories and 1e-8 against the oracle on the bench ensemble."""
+import numpy as np
+import pytest
+
+from conftest import SCENARIOS, cfg_columns, golden_json, golden_npz, relerr
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-6  # stated fp64 tolerance of the north star
+
+
+def _ens_from_golden(wt, g, n):
+    cols = cfg_columns(g["cfg"], g["cfg_fields"])
+    return wt.ReactorEnsemble(cols, n_zones=n), cols
+
+
+def _initial(cols, S, n):
+    shape = (S, n)
+    return (np.broadcast_to(np.asarray(cols["initial_pH"], dtype=float)[:, None], shape).copy(),
+            np.broadcast_to(np.asarray(cols["initial_chlorine"], dtype=float)[:, None], shape).copy(),
+            np.broadcast_to(np.asarray(cols["temperature"], dtype=float)[:, None], shape).copy())
+
+
+@pytest.mark.parametrize("n", [4, 8, 20])
+def test_rhs_vs_reference_and_oracle(gpu, wt, oracle, n):
+    g = golden_npz(f"g2_rhs_n{n}.npz")
+    ens, cols = _ens_from_golden(wt, g, n)
+    ens.set_boundary(np.ascontiguousarray(g["bc"].T))
+    y = g["y"]
+    dpH, dCl, dT, fl = ens.derivatives(y[:, :n], y[:, n:2 * n], y[:, 2 * n:])
+    assert not fl.any()
+    f = np.concatenate([dpH, dCl, dT], axis=1)
+    ref = g["f"]
+    par = ens.constants
+    for c in range(y.shape[0]):
+        fo, _ = oracle.rhs(n, par[:, c], g["bc"][c], y[c])
+        K = par[wt.params.P_KEX, c]
+        H = 10.0 ** (-y[c][:n])
+        mag = np.concatenate([np.abs(ref[c][:n]) + 4 * K * H.max() / 1e-4,
+                              np.abs(ref[c][n:2 * n]) + 4 * K * np.abs(y[c][n:2 * n]).max() + 1e-300,
+                              np.abs(ref[c][2 * n:]) + 4 * K * np.abs(y[c][2 * n:]).max()])
+        assert np.all(np.abs(f[c] - ref[c]) <= 2e-12 * mag), f"case {c} vs reference"
+        assert np.all(np.abs(f[c] - fo) <= 2e-12 * mag), f"case {c} vs oracle"
+    ens.close()
+
+
+def test_rhs_flags_temperature_range(gpu, wt):
+    ens = wt.ReactorEnsemble([wt.ReactorConfiguration(n_zones=4) for _ in range(3)])
+    ens.set_boundary(wt.BoundaryConditions())
+    T = np.full((3, 4), 20.0); T[1, 2] = 100.5; T[2, 0] = -0.1
+    _, _, _, fl = ens.derivatives(np.full((3, 4), 7.0), np.full((3, 4), 2.0), T)
+    assert list(fl) == [0, 1, 1]
+    r = wt.IntegratedCSTR(wt.ReactorConfiguration(n_zones=4))
+    with pytest.raises(ValueError, match="outside liquid water range"):
+        r.derivatives(0.0, np.concatenate([np.full(4, 7.0), np.full(4, 2.0), [20, 20, 101, 20]]), wt.BoundaryConditions())
+    ens.close()
+
+
+@pytest.mark.parametrize("n", [4, 8, 20])
+@pytest.mark.parametrize("scen", SCENARIOS)
+def test_dropin_trajectory_vs_reference(gpu, wt, n, scen):
+    """IntegratedCSTR.step() (one-reactor drop-in) step by step against the
+    reference trajectory, including scipy's decision counters on every step."""
+    g = golden_npz(f"g3_traj_{scen}_n{n}.npz")
+    fields = [str(x) for x in g["cfg_fields"]]
+    kw = {k: (bool(v) if k == "enable_thermal_stratification" else (int(v) if k == "n_zones" else float(v)))
+          for k, v in zip(fields, g["cfg"])}
+    r = wt.IntegratedCSTR(wt.ReactorConfiguration(**kw))
+    b = wt.BoundaryConditions(**{k: float(v) for k, v in zip(wt.params.BOUNDARY_FIELDS, g["bc"])})
+    dt = float(g["dt"])
+    traj, stats = g["traj"], g["stats"]
+    nst = min(traj.shape[0] - 1, 250)
+    worst = np.zeros(3)
+    mismatched = 0
+    prev = r.state
+    for k in range(nst):
+        s = r.step(dt, b)
+        assert s is prev                                         # same mutable object (reactor.py:509)
+        got = np.stack([s.pH, s.chlorine, s.temperature])
+        worst = np.maximum(worst, np.max(np.abs(got - traj[k + 1]) / np.abs(traj[k + 1]), axis=1))
+        st = r._ens.solver_stats()[0]
+        mismatched += int(tuple(st[:4]) != tuple(stats[k][:4]))
+        assert abs(s.time - g["time"][k]) < 1e-9 and s.flow_rate == g["flow"][k]
+        der = np.stack([s.H_concentration, s.density, s.chlorine_decay_rate])
+        assert relerr(der, g["derived"][k]) < TOL
+    assert np.all(worst < 1e-7), worst
+    assert mismatched == 0, f"{mismatched} of {nst} steps took a different solver decision sequence"
+
+
+@pytest.mark.parametrize("n", [4, 8, 20])
+def test_synthetic_sample_vs_reference(gpu, wt, n):
+    """First 64 reactors of the bench ensemble, 50 steps, against the reference."""
+    g = golden_npz(f"g6_ensemble_n{n}.npz")
+    S, steps, every = int(g["n_reactors"]), int(g["steps"]), int(g["every"])
+    cols, bc = wt.make_ensemble(S)
+    ens = wt.ReactorEnsemble(cols, n_zones=n)
+    ens.set_boundary(bc)
+    for k in range(steps // every):
+        es = ens.step(1.0, n_steps=every, fused=(k % 2 == 0))
+        snap = g["snaps"][k]
+        assert not es.status.any()
+        assert relerr(es.pH, snap[:, 0]) < 1e-7
+        assert relerr(es.chlorine, snap[:, 1]) < 1e-7
+        assert relerr(es.temperature, snap[:, 2]) < 1e-7
+    # decision counters of the last step
+    st = ens.solver_stats()
+    assert np.array_equal(st[:, :4], g["stats"][:, steps - 1, :4])
+    ens.close()
+
+
+@pytest.mark.parametrize("n,N", [(4, 10000), (8, 10000), (20, 10000)])
+def test_full_size_ensemble_vs_oracle(gpu, wt, oracle, n, N):
+    """BASELINE configs 2-4 at full size: every reactor, every zone against the
+    oracle after 8 steps, plus size-independent properties: launch-shape
+    invariance (fused == stepwise, bitwise), run-to-run determinism, and
+    independence of a reactor from its neighbours in the wavefront."""
+    cols, bc = wt.make_ensemble(N)
+    ens = wt.ReactorEnsemble(cols, n_zones=n)
+    ens.set_boundary(bc)
+    st0 = ens.state
+    steps = 8
+    es = ens.step(1.0, n_steps=steps, fused=True)
+    pH, Cl, T, t, ost = oracle.ensemble_step(n, ens.constants, bc, 1.0, steps, st0.pH, st0.chlorine,
+                                             st0.temperature, st0.time, nthreads=16)
+    assert np.array_equal(es.status != 0, ost != 0)
+    ok = ost == 0
+    err = np.stack([np.abs(es.pH - pH) / np.abs(pH), np.abs(es.chlorine - Cl) / np.abs(Cl),
+                    np.abs(es.temperature - T) / np.abs(T)])[:, ok]
+    assert err.max() < TOL
+    # report-style tight bound: all but a handful of (reactor, zone) samples agree to 1e-9
+    assert np.mean(err < 1e-9) > 0.9999
+    assert np.allclose(es.time[ok], steps * 1.0)
+    # stepwise launches give bitwise the same answer as the fused launch
+    ens.set_state(st0.pH, st0.chlorine, st0.temperature, st0.time)
+    es2 = ens.step(1.0, n_steps=steps, fused=False)
+    for a, b in ((es.pH, es2.pH), (es.chlorine, es2.chlorine), (es.temperature, es2.temperature),
+                 (es.H_concentration, es2.H_concentration), (es.density, es2.density),
+                 (es.chlorine_decay_rate, es2.chlorine_decay_rate)):
+        assert np.array_equal(a, b)
+    ens.close()
+    # a reactor's result does not depend on which reactors share its wavefront
+    perm = np.random.default_rng(7).permutation(N)[:2000]
+    sub_cols = {k: v[perm] for k, v in cols.items()}
+    ens_p = wt.ReactorEnsemble(sub_cols, n_zones=n)
+    ens_p.set_boundary(np.ascontiguousarray(bc[:, perm]))
+    esp = ens_p.step(1.0, n_steps=steps, fused=True)
+    assert np.array_equal(esp.pH, es.pH[perm]) and np.array_equal(esp.chlorine, es.chlorine[perm])
+    assert np.array_equal(esp.temperature, es.temperature[perm])
+    ens_p.close()
+
+
+@pytest.mark.parametrize("n,N", [(2, 5), (3, 33), (5, 1), (7, 100), (16, 9), (31, 4), (64, 3)])
+def test_ragged_shapes_vs_oracle(gpu, wt, oracle, n, N):
+    """Zone counts that do not divide 64, a single reactor, the 64-zone maximum."""
+    cols, bc = wt.make_ensemble(N, seed=99)
+    ens = wt.ReactorEnsemble(cols, n_zones=n)
+    ens.set_boundary(bc)
+    st0 = ens.state
+    es = ens.step(1.0, n_steps=5)
+    pH, Cl, T, t, ost = oracle.ensemble_step(n, ens.constants, bc, 1.0, 5, st0.pH, st0.chlorine, st0.temperature,
+                                             st0.time, nthreads=4)
+    assert np.array_equal(es.status, ost.astype(np.uint32))
+    assert relerr(es.pH, pH) < 1e-7 and relerr(es.chlorine, Cl) < 1e-7 and relerr(es.temperature, T) < 1e-7
+    ens.close()
+
+
+def test_zone_count_limits(gpu, wt):
+    with pytest.raises(ValueError, match="at least 2 zones"):
+        wt.ReactorEnsemble({"volume": np.array([1000.0])}, n_zones=1)
+    native = gpu
+    with pytest.raises(native.WtError):
+        wt.ReactorEnsemble({"volume": np.array([1000.0])}, n_zones=65)
+
+
+def test_cold_run_freezes_like_reference(gpu, wt):
+    """A reactor cooled below 0 degC: the reference raises ValueError out of step()
+    at a known step index and leaves the state untouched."""
+    g = golden_json("g4_faults.json")["cold_run"]
+    cfg = wt.ReactorConfiguration(**g["config"])
+    b = wt.BoundaryConditions(**dict(zip(wt.params.BOUNDARY_FIELDS, g["bc"])))
+    r = wt.IntegratedCSTR(cfg)
+    for k in range(200):
+        try:
+            s = r.step(1.0, b)
+        except ValueError as e:
+            assert "outside liquid water range" in str(e)
+            assert k == g["raise_step_index"]
+            got = np.concatenate([r.state.pH, r.state.chlorine, r.state.temperature])
+            assert relerr(got, np.concatenate(g["state_before_raise"])) < 1e-9
+            assert r.state.time == g["time_before_raise"]
+            break
+    else:
+        pytest.fail("no ValueError")
+    # ensemble semantics: the flagged reactor is frozen, its neighbours keep stepping
+    ens = wt.ReactorEnsemble([cfg, wt.ReactorConfiguration(n_zones=4)])
+    ens.set_boundary([b, wt.BoundaryConditions()])
+    es = ens.step(1.0, n_steps=60)
+    assert es.status[0] & 1 and es.status[1] == 0
+    assert es.time[0] == g["raise_step_index"] and es.time[1] == 60.0
+    ens.close()
+
+
+def test_batch_mode_construction_quirk(gpu, wt):
+    assert golden_json("g4_faults.json")["batch_construction"] == "TypeError"
+    with pytest.raises(TypeError):
+        wt.IntegratedCSTR(wt.ReactorConfiguration(flow_rate=0.0))
+
+
+def test_clamps_and_host_state_edits(gpu, wt, oracle):
+    """State edited between steps is honoured (reactor.py:467-469); negative chlorine is
+    clipped after the derived quantities are taken (reactor.py:503-507,534-536)."""
+    cfg = wt.ReactorConfiguration(n_zones=4)
+    b = wt.BoundaryConditions(inlet_chlorine=0.0)
+    bv = np.array([getattr(b, k) for k in wt.params.BOUNDARY_FIELDS])
+    r = wt.IntegratedCSTR(cfg)
+    r.step(1.0, b)
+    T1 = r.state.temperature.copy()
+    # the host overwrites part of the state: zone 3 gets a chlorine value that decays below zero
+    r.state.chlorine = np.array([2.0, 2.0, 2.0, -1e-3])
+    r.state.pH = np.array([7.0, 7.1, 7.2, 7.3])
+    s = r.step(1.0, b)
+    par = r._ens.constants[:, 0]
+    y0 = np.concatenate([[7.0, 7.1, 7.2, 7.3], [2.0, 2.0, 2.0, -1e-3], T1])
+    yo, to, der, status = oracle.step(4, par, bv, 1.0, y0, 1.0)
+    assert s.time == 2.0 == to
+    got = np.concatenate([s.pH, s.chlorine, s.temperature])
+    # Radau's own tolerances (rtol 1e-6, atol 1e-8) bound what "the same solve" means here
+    assert np.all(np.abs(got - yo) <= 1e-6 * np.abs(yo) + 1e-8)
+    assert int(r._ens.status()[0]) == status
+    assert np.all(s.chlorine >= 0)
+    # clamp flag: force a negative result (large negative chlorine everywhere, no inlet)
+    ens = wt.ReactorEnsemble([cfg])
+    ens.set_boundary(b)
+    ens.set_state(np.full((1, 4), 7.0), np.full((1, 4), -0.5), np.full((1, 4), 20.0), np.array([0.0]))
+    es = ens.step(1.0)
+    yo, to, der, status = oracle.step(4, par, bv, 1.0, np.concatenate([np.full(4, 7.0), np.full(4, -0.5), np.full(4, 20.0)]), 0.0)
+    assert status & oracle.ST_CLAMP_CL and int(es.status[0]) == status
+    assert np.all(es.chlorine == 0.0) and np.all(yo[4:8] == 0.0)
+    assert relerr(es.pH[0], yo[:4]) < 1e-9 and relerr(es.temperature[0], yo[8:]) < 1e-9
+    ens.close()
+
+
+def test_step_argument_errors(gpu, wt):
+    ens = wt.ReactorEnsemble([wt.ReactorConfiguration(n_zones=4)])
+    with pytest.raises(ValueError, match="boundary"):
+        ens.step(1.0)
+    ens.set_boundary(wt.BoundaryConditions())
+    with pytest.raises(ValueError, match="max_step"):
+        ens.step(0.0)
+    with pytest.raises(ValueError, match="max_step"):
+        ens.step(-1.0)
+    ens.close()
+
+
+def test_ph_solver_vs_reference(gpu, wt, oracle):
+    g = golden_json("g5_ph_solver.json")
+    cases = g["cases"]
+    alk = np.array([c["alkalinity"] for c in cases]); ct = np.array([c["total_carbonate"] for c in cases])
+    T = np.array([c["temperature"] for c in cases]); guess = np.array([c["guess"] for c in cases])
+    pH, it, rc = wt.solve_pH(alk, ct, T, guess)
+    for i, c in enumerate(cases):
+        if c["rc"] == 0:
+            assert rc[i] == 0 and abs(pH[i] - c["pH"]) < 1e-9, c
+        else:
+            assert rc[i] != 0
+    chem = wt.AqueousChemistry(wt.BufferSystem(100.0, 2.0, 20.0))
+    pH_eq = chem.calculate_pH()
+    assert abs(pH_eq - g["pH_eq_default"]) < 1e-9
+    assert abs(chem.add_acid(1000, 0.001, pH_eq) - g["add_acid_1000L_0p001mol"]) < 1e-9
+    assert abs(chem.add_base(1000, 0.001, pH_eq) - g["add_base_1000L_0p001mol"]) < 1e-9
+    # large batch against the oracle, including guesses that converge to different roots
+    rng = np.random.default_rng(5)
+    M = 20000
+    alk, ct, T, guess = rng.uniform(50, 200, M), rng.uniform(1, 4, M), rng.uniform(5, 35, M), rng.uniform(2, 12, M)
+    pH, it, rc = wt.solve_pH(alk, ct, T, guess)
+    P = wt.params
+    Kw = P.water_ionization_constant(T); Ka1 = P._pow10_neg(P.carbonate_pKa(T, 1)); Ka2 = P._pow10_neg(P.carbonate_pKa(T, 2))
+    checked = 0
+    for i in range(0, M, 97):
+        po, ito, rco = oracle.calculate_pH(Kw[i], Ka1[i], Ka2[i], ct[i] / 1000.0, alk[i], guess[i])
+        if rco == 0 and ito <= 12:
+            # regular Newton path: same root, same iteration count
+            assert rc[i] == 0 and it[i] == ito and abs(pH[i] - po) < 1e-9
+            checked += 1
+        elif rc[i] == 0:
+            # the iteration is chaotic for this guess (f is non-monotone and the update is clipped
+            # to [0,14]; the oracle itself needs > 12 iterations or fails): a 1-ulp difference picks
+            # another path, so only require that what the GPU returns is a root of the charge balance
+            H = 10.0 ** (-pH[i])
+            D = H * H + Ka1[i] * H + Ka1[i] * Ka2[i]
+            f = H - Kw[i] / H + (Ka1[i] * H / D + 2 * Ka1[i] * Ka2[i] / D) * ct[i] / 1000.0 - alk[i] / 50000.0
+            assert abs(f) < 1e-8
+    assert checked > 150

@@ -1,0 +1,113 @@
+"""Host-side logic that needs no GPU: dataclasses mirror the reference's API,
+SoA packing, synthetic generator, the shared library exports its C ABI and
+refuses to compute without a device."""
+import ctypes as C
+import dataclasses
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, golden_json
+
+
+def test_dataclass_defaults_match_reference(wt):
+    # reactor.py:61-89, :169-186 defaults (values recorded in SURVEY.md Appendix A)
+    cfg = wt.ReactorConfiguration()
+    assert (cfg.volume, cfg.height, cfg.diameter, cfg.n_zones) == (1000.0, 2.0, 0.798, 5)
+    assert (cfg.flow_rate, cfg.impeller_speed, cfg.impeller_diameter, cfg.power_number) == (5.0, 60.0, 0.3, 5.0)
+    assert (cfg.initial_pH, cfg.alkalinity, cfg.total_carbonate, cfg.initial_chlorine, cfg.temperature) == (7.0, 100.0, 2.0, 2.0, 20.0)
+    assert cfg.enable_thermal_stratification is True
+    b = wt.BoundaryConditions()
+    assert [getattr(b, k) for k in wt.params.BOUNDARY_FIELDS] == [5.0, 7.5, 0.0, 20.0, 0.0, 0.1, 0.0, 50.0, 20.0, 0.0]
+    assert [f.name for f in dataclasses.fields(b)] == list(wt.params.BOUNDARY_FIELDS)
+    s = wt.ReactorState()
+    assert s.pH.shape == (5,) and np.all(s.H_concentration == 10 ** (-s.pH))
+    assert np.all(s.density == 998.2) and np.all(s.chlorine_decay_rate == 0.0001)
+    assert set(s.state_dict()) >= {"time", "pH", "chlorine", "temperature", "flow_rate", "H_concentration"}
+    assert wt.PhysicsEngine is wt.IntegratedCSTR
+
+
+def test_config_validate_errors(wt):
+    g = golden_json("g4_faults.json")
+    with pytest.raises(ValueError, match="Volume mismatch"):
+        wt.ReactorConfiguration(volume=500.0).validate()
+    assert g["volume_mismatch"] == "ValueError"
+    with pytest.raises(AssertionError):
+        wt.ReactorConfiguration(temperature=45.0).validate()
+    with pytest.raises(AssertionError):
+        wt.ReactorConfiguration(initial_chlorine=11.0).validate()
+    wt.ReactorConfiguration().validate()
+
+
+def test_boundary_block_packing(wt):
+    bb = wt.boundary_block(wt.BoundaryConditions(acid_flow_rate=0.5), 3)
+    assert bb.shape == (10, 3) and np.all(bb[4] == 0.5) and np.all(bb[0] == 5.0)
+    seq = [wt.BoundaryConditions(inlet_pH=6.0 + i) for i in range(3)]
+    assert np.array_equal(wt.boundary_block(seq, 3)[1], [6.0, 7.0, 8.0])
+    d = wt.boundary_block({"inlet_temperature": np.array([1.0, 2.0, 3.0])}, 3)
+    assert np.array_equal(d[3], [1.0, 2.0, 3.0]) and np.all(d[7] == 50.0)
+    with pytest.raises(ValueError):
+        wt.boundary_block(seq, 4)
+    with pytest.raises(ValueError):
+        wt.boundary_block(np.zeros((9, 3)), 3)
+
+
+def test_synthetic_ensemble_is_prefix_stable_and_in_range(wt):
+    c1, b1 = wt.make_ensemble(64)
+    c2, b2 = wt.make_ensemble(1000)
+    for k in c1:
+        assert np.array_equal(c1[k], c2[k][:64])
+    assert np.array_equal(b1, b2[:, :64])
+    c3, b3 = wt.make_ensemble(100, start=900)
+    assert np.array_equal(b3, b2[:, 900:])
+    assert c2["initial_pH"].min() >= 6.5 and c2["initial_pH"].max() <= 8.5
+    assert c2["temperature"].min() >= 10 and c2["temperature"].max() <= 30
+    assert np.all((b2[4] == 0) | ((b2[4] > 0) & (b2[4] <= 2)))
+    assert 0.35 < np.mean(b2[4] == 0) < 0.65 and 0.6 < np.mean(b2[9] == 0) < 0.9
+    assert np.all(b2[0] <= 12.0) and np.all(b2[0] >= 1.6)
+
+
+def test_shard_bounds_cover_everything(wt):
+    for N in (1, 7, 100, 100000):
+        for W in (1, 2, 3, 8):
+            spans = [wt.shard_bounds(N, W, r) for r in range(W)]
+            assert spans[0][0] == 0 and spans[-1][1] == N
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(W - 1))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        wt.shard_bounds(10, 2, 2)
+
+
+def test_library_exports_every_declared_symbol(native):
+    """Every function declared in include/wtphys.h is exported by libwtphys.so."""
+    hdr = open(os.path.join(ROOT, "include", "wtphys.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    names = sorted(set(re.findall(r"\b(wt_[a-z_0-9]+)\s*\(", hdr)))
+    assert len(names) >= 20
+    lib = C.CDLL(native.LIB_PATH)
+    for name in names:
+        assert hasattr(lib, name), f"{name} not exported"
+    assert lib.wt_abi_version() == 1
+
+
+def test_no_silent_cpu_fallback(native, wt):
+    """Without a HIP device the product path must fail loudly."""
+    if native.device_count() > 0:
+        pytest.skip("a GPU is visible; the loud-failure path is for GPU-less hosts")
+    with pytest.raises(native.WtError) as ei:
+        wt.ReactorEnsemble([wt.ReactorConfiguration(n_zones=4)])
+    assert ei.value.code == native.WT_E_NOGPU
+    with pytest.raises(native.WtError):
+        wt.solve_pH(100.0, 2.0, 20.0)
+
+
+def test_product_package_never_imports_oracle():
+    pkg = os.path.join(ROOT, "ics-wt-physicsengine_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "wt_oracle" not in text and "libwtoracle" not in text, f
