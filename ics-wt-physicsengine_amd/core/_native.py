@@ -82,6 +82,7 @@ def lib():
     L.wt_ensemble_set_stream.argtypes = [vp, vp]
     L.wt_ensemble_timer_start.argtypes = [vp]
     L.wt_ensemble_timer_stop.argtypes = [vp, C.POINTER(C.c_float)]
+    L.wt_selftest_shuffles.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int)]
     L.wt_ensemble_size.argtypes = [vp]
     L.wt_ensemble_size.restype = C.c_int64
     L.wt_ensemble_zones.argtypes = [vp]
@@ -91,7 +92,7 @@ def lib():
                  "wt_ensemble_get_state", "wt_ensemble_get_derived", "wt_ensemble_get_status",
                  "wt_ensemble_clear_status", "wt_ensemble_get_stats", "wt_ensemble_rhs",
                  "wt_ensemble_export_state_device", "wt_ensemble_set_stream", "wt_ensemble_timer_start",
-                 "wt_ensemble_timer_stop", "wt_ensemble_zones", "wt_ph_solve"):
+                 "wt_ensemble_timer_stop", "wt_ensemble_zones", "wt_ph_solve", "wt_selftest_shuffles"):
         getattr(L, name).restype = C.c_int
     if L.wt_abi_version() != 1:
         raise ImportError("libwtphys.so ABI version mismatch; rebuild it")

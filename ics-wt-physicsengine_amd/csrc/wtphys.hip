@@ -27,33 +27,6 @@ int fail(int code, const std::string &msg)
             return fail(WT_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));       \
     } while (0)
 
-// radau.py:11-40 and common.py:248-253, evaluated with the same expressions
-wt::RadauConsts make_consts()
-{
-    wt::RadauConsts c;
-    const double S6 = std::pow(6.0, 0.5);
-    c.C[0] = (4 - S6) / 10; c.C[1] = (4 + S6) / 10; c.C[2] = 1.0;
-    c.E[0] = (-13 - 7 * S6) / 3; c.E[1] = (-13 + 7 * S6) / 3; c.E[2] = -1.0 / 3;
-    c.MU_REAL = 3 + std::pow(3.0, 2.0 / 3) - std::pow(3.0, 1.0 / 3);
-    c.MU_CR = 3 + 0.5 * (std::pow(3.0, 1.0 / 3) - std::pow(3.0, 2.0 / 3));
-    c.MU_CI = -0.5 * (std::pow(3.0, 5.0 / 6) + std::pow(3.0, 7.0 / 6));
-    const double T[3][3] = {{0.09443876248897524, -0.14125529502095421, 0.03002919410514742},
-                            {0.25021312296533332, 0.20412935229379994, -0.38294211275726192},
-                            {1, 1, 0}};
-    const double TI[3][3] = {{4.17871859155190428, 0.32768282076106237, 0.52337644549944951},
-                             {-4.17871859155190428, -0.32768282076106237, 0.47662355450055044},
-                             {0.50287263494578682, -2.57192694985560522, 0.59603920482822492}};
-    const double P[3][3] = {{13.0 / 3 + 7 * S6 / 3, -23.0 / 3 - 22 * S6 / 3, 10.0 / 3 + 5 * S6},
-                            {13.0 / 3 - 7 * S6 / 3, -23.0 / 3 + 22 * S6 / 3, 10.0 / 3 - 5 * S6},
-                            {1.0 / 3, -8.0 / 3, 10.0 / 3}};
-    std::memcpy(c.T, T, sizeof T); std::memcpy(c.TI, TI, sizeof TI); std::memcpy(c.P, P, sizeof P);
-    const double EPS = 2.220446049250313e-16;
-    c.NJ_REJECT = std::pow(EPS, 0.875); c.NJ_SMALL = std::pow(EPS, 0.75); c.NJ_BIG = std::pow(EPS, 0.25);
-    c.NJ_MINF = 1e3 * EPS; c.NJ_F0 = std::pow(EPS, 0.5);
-    c.newton_tol = std::fmax(10 * EPS / wt::RTOL, std::fmin(0.03, std::pow(wt::RTOL, 0.5)));
-    return c;
-}
-
 int levels_for(int n)
 {
     int l = 0;
@@ -75,7 +48,6 @@ struct wt_ensemble {
     int32_t *stats = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool have_bc = false, have_state = false;
-    wt::RadauConsts rc;
 };
 
 namespace {
@@ -88,20 +60,32 @@ wt::StepArgs make_args(const wt_ensemble *h, double dt, int n_steps)
     a.pH = h->pH; a.Cl = h->Cl; a.T = h->T; a.time = h->time; a.flow = h->flow;
     a.dH = h->dH; a.dRho = h->dRho; a.dK = h->dK;
     a.status = h->status; a.stats = h->stats;
-    a.dt = dt; a.n_steps = n_steps; a.rc = h->rc;
+    a.dt = dt; a.n_steps = n_steps;
     return a;
 }
+
+bool row_mode(int n) { return n == 2 || n == 4 || n == 8 || n == 16; }
 
 void launch_step(const wt_ensemble *h, const wt::StepArgs &a)
 {
     const unsigned grid = (unsigned)((h->N + h->R - 1) / h->R);
-    switch (levels_for(h->n)) {
-    case 1: hipLaunchKernelGGL(wt::step_kernel<1>, dim3(grid), dim3(64), 0, h->stream, a); break;
-    case 2: hipLaunchKernelGGL(wt::step_kernel<2>, dim3(grid), dim3(64), 0, h->stream, a); break;
-    case 3: hipLaunchKernelGGL(wt::step_kernel<3>, dim3(grid), dim3(64), 0, h->stream, a); break;
-    case 4: hipLaunchKernelGGL(wt::step_kernel<4>, dim3(grid), dim3(64), 0, h->stream, a); break;
-    case 5: hipLaunchKernelGGL(wt::step_kernel<5>, dim3(grid), dim3(64), 0, h->stream, a); break;
-    default: hipLaunchKernelGGL(wt::step_kernel<6>, dim3(grid), dim3(64), 0, h->stream, a); break;
+    const dim3 g(grid), b(64);
+    const int lv = levels_for(h->n);
+    if (row_mode(h->n)) { // n in {2,4,8,16}: every cross-lane move is a DPP row operation
+        switch (lv) {
+        case 1: hipLaunchKernelGGL((wt::step_kernel<1, true>), g, b, 0, h->stream, a); break;
+        case 2: hipLaunchKernelGGL((wt::step_kernel<2, true>), g, b, 0, h->stream, a); break;
+        case 3: hipLaunchKernelGGL((wt::step_kernel<3, true>), g, b, 0, h->stream, a); break;
+        default: hipLaunchKernelGGL((wt::step_kernel<4, true>), g, b, 0, h->stream, a); break;
+        }
+    } else {
+        switch (lv) {
+        case 2: hipLaunchKernelGGL((wt::step_kernel<2, false>), g, b, 0, h->stream, a); break;
+        case 3: hipLaunchKernelGGL((wt::step_kernel<3, false>), g, b, 0, h->stream, a); break;
+        case 4: hipLaunchKernelGGL((wt::step_kernel<4, false>), g, b, 0, h->stream, a); break;
+        case 5: hipLaunchKernelGGL((wt::step_kernel<5, false>), g, b, 0, h->stream, a); break;
+        default: hipLaunchKernelGGL((wt::step_kernel<6, false>), g, b, 0, h->stream, a); break;
+        }
     }
 }
 
@@ -136,7 +120,6 @@ int wt_ensemble_create(int64_t n_reactors, int n_zones, int device, const double
     HIP_TRY(hipSetDevice(device));
     wt_ensemble *h = new wt_ensemble();
     h->N = n_reactors; h->n = n_zones; h->R = 64 / n_zones; h->device = device;
-    h->rc = make_consts();
     const size_t N = (size_t)n_reactors, nz = (size_t)n_zones;
     auto cleanup = [&]() { wt_ensemble_destroy(h); };
 #define ALLOC(ptr, bytes)                                                                   \
@@ -337,7 +320,8 @@ int wt_ensemble_rhs(wt_ensemble *h, const double *pH, const double *Cl, const do
         a.pH = buf; a.Cl = buf + cnt; a.T = buf + 2 * cnt;
         a.dpH = buf + 3 * cnt; a.dCl = buf + 4 * cnt; a.dT = buf + 5 * cnt; a.flags = fl;
         const unsigned grid = (unsigned)((h->N + h->R - 1) / h->R);
-        hipLaunchKernelGGL(wt::rhs_kernel, dim3(grid), dim3(64), 0, h->stream, a);
+        if (row_mode(h->n)) hipLaunchKernelGGL(wt::rhs_kernel<true>, dim3(grid), dim3(64), 0, h->stream, a);
+        else hipLaunchKernelGGL(wt::rhs_kernel<false>, dim3(grid), dim3(64), 0, h->stream, a);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpyAsync(dpH, buf + 3 * cnt, b, hipMemcpyDeviceToHost, h->stream);
@@ -377,6 +361,28 @@ int wt_ensemble_timer_stop(wt_ensemble *h, float *elapsed_ms)
     HIP_TRY(hipEventRecord(h->ev1, h->stream));
     HIP_TRY(hipEventSynchronize(h->ev1));
     HIP_TRY(hipEventElapsedTime(elapsed_ms, h->ev0, h->ev1));
+    return WT_OK;
+}
+
+int wt_selftest_shuffles(int device, int n_zones, int *mismatches)
+{
+    if (!mismatches || n_zones < 2 || n_zones > WT_MAX_ZONES) return fail(WT_E_ARG, "bad argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(WT_E_NOGPU, "no HIP device available: libwtphys has no CPU path");
+    HIP_TRY(hipSetDevice(device));
+    int *d = nullptr;
+    HIP_TRY(hipMalloc((void **)&d, 64 * sizeof(int)));
+    wt::ShuffleTestArgs a{n_zones, d};
+    if (row_mode(n_zones)) hipLaunchKernelGGL(wt::shuffle_selftest_kernel<true>, dim3(1), dim3(64), 0, 0, a);
+    else hipLaunchKernelGGL(wt::shuffle_selftest_kernel<false>, dim3(1), dim3(64), 0, 0, a);
+    int host[64];
+    hipError_t e = hipMemcpy(host, d, sizeof host, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(WT_E_HIP, hipGetErrorString(e));
+    int total = 0;
+    for (int i = 0; i < 64; ++i) total += host[i];
+    *mismatches = total;
     return WT_OK;
 }
 

@@ -125,6 +125,10 @@ int wt_ensemble_set_stream(wt_ensemble *h, void *hip_stream);
 int wt_ensemble_timer_start(wt_ensemble *h);
 int wt_ensemble_timer_stop(wt_ensemble *h, float *elapsed_ms /* synchronises */);
 
+/* Self-test of the kernel's cross-lane primitives (DPP row / wave shifts, segment
+ * sums) against ds_bpermute for a given zone count; *mismatches must come back 0. */
+int wt_selftest_shuffles(int device, int n_zones, int *mismatches);
+
 int64_t wt_ensemble_size(const wt_ensemble *h);
 int wt_ensemble_zones(const wt_ensemble *h);
 

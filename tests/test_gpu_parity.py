@@ -295,3 +295,12 @@ def test_ph_solver_vs_reference(gpu, wt, oracle):
             f = H - Kw[i] / H + (Ka1[i] * H / D + 2 * Ka1[i] * Ka2[i] / D) * ct[i] / 1000.0 - alk[i] / 50000.0
             assert abs(f) < 1e-8
     assert checked > 150
+
+
+@pytest.mark.parametrize("n", [2, 3, 4, 5, 7, 8, 16, 20, 33, 64])
+def test_cross_lane_primitives(gpu, n):
+    """DPP row/wave shifts and the segment reduction agree with ds_bpermute on this GPU."""
+    import ctypes as C
+    m = C.c_int(-1)
+    gpu.check(gpu.lib().wt_selftest_shuffles(0, n, C.byref(m)))
+    assert m.value == 0
