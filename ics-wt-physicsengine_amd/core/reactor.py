@@ -276,6 +276,20 @@ class ReactorEnsemble:
             raise
         return self.state if download else None
 
+    def set_schedule(self, n_streams: int, chunk_steps: int = 10) -> None:
+        """Advance the ensemble as ``n_streams`` contiguous reactor ranges on internal HIP
+        streams, at most ``chunk_steps`` outer steps per launch (0 = one launch per call)."""
+        _native.check(_native.lib().wt_ensemble_set_schedule(self._h, int(n_streams), int(chunk_steps)))
+
+    def launch_timing(self, enable: bool = True) -> None:
+        _native.check(_native.lib().wt_ensemble_launch_timing(self._h, 1 if enable else 0))
+
+    def launch_stats(self):
+        """(number of step-kernel launches, sum of their durations [ms], longest [ms]) since the last call."""
+        n, s, m = C.c_int64(0), C.c_double(0.0), C.c_double(0.0)
+        _native.check(_native.lib().wt_ensemble_launch_stats(self._h, C.byref(n), C.byref(s), C.byref(m)))
+        return int(n.value), float(s.value), float(m.value)
+
     def synchronize(self) -> None:
         _native.check(_native.lib().wt_ensemble_synchronize(self._h))
 
@@ -315,6 +329,21 @@ class ReactorEnsemble:
         _native.check(_native.lib().wt_ensemble_rhs(self._h, *[_native.dptr(x) for x in a], *[_native.dptr(x) for x in out],
                                                    fl.ctypes.data_as(C.POINTER(C.c_uint32))))
         return out[0], out[1], out[2], fl
+
+    def wave_diag(self) -> Optional[np.ndarray]:
+        """Per-wavefront diagnostics of the last launch, (n_waves, 4) int64:
+        loop trips, Newton trips, shader clocks, 100 MHz wall ticks.  The first
+        call only switches recording on and returns None."""
+        nw = C.c_int64(0)
+        L = _native.lib()
+        if not getattr(self, "_diag_on", False):
+            _native.check(L.wt_ensemble_wave_diag(self._h, None, 0, C.byref(nw)))
+            self._diag_on = True
+            return None
+        _native.check(L.wt_ensemble_wave_diag(self._h, None, 0, C.byref(nw)))
+        out = np.zeros((nw.value, 4), dtype=np.int64)
+        _native.check(L.wt_ensemble_wave_diag(self._h, out.ctypes.data_as(C.POINTER(C.c_int64)), nw.value, C.byref(nw)))
+        return out
 
     def export_state_device(self, device_ptr: int) -> None:
         """Async device-to-device copy of [pH, Cl, T] (3, N, n) into caller device memory."""

@@ -72,7 +72,8 @@ constexpr double INV_TREF = 0x1.bf1da5ca77e69p-9;  // 1/293.15
 } // namespace rc
 
 struct StepArgs {
-    int64_t N;
+    int64_t N;        // reactors in the ensemble (row stride of par / bc)
+    int64_t r0, r1;   // this launch advances reactors [r0, r1)
     int n;            // zones per reactor
     int R;            // reactors per wavefront = 64 / n
     const double *par; // [WT_NP][N]
@@ -82,6 +83,7 @@ struct StepArgs {
     double *dH, *dRho, *dK; // derived [N][n]
     uint32_t *status;    // [N]
     int32_t *stats;      // [N][5] or nullptr
+    int64_t *wave_diag;  // [n_waves][4] or nullptr: trips, Newton trips, shader clocks, wall clock (100 MHz)
     double dt;
     int n_steps;
 };
@@ -304,16 +306,29 @@ struct Jac {
     double pp[3], cc[3], tt[3], pt[3], ct[3], cp;
 };
 
-// PCR-factored tridiagonal systems (real and complex shift)
-template <int LV> struct TriR { double al[LV], ga[LV], invd; };
-template <int LV> struct TriC { double alr[LV], ali[LV], gar[LV], gai[LV], invdr, invdi; };
+// PCR-factored tridiagonal systems (real and complex shift) live in LDS, not in
+// registers: slot-major [slot][64 lanes] doubles, so lane l of a wavefront touches
+// bank pair (2l, 2l+1) of every slot -- conflict-free ds_read_b64 / ds_write_b64.
+// A factor is written once per (h, J) and read once per solve, so LDS traffic is
+// off the fp64 VALU pipe that bounds this kernel, and the register file keeps
+// room for two wavefronts per SIMD.
+struct LdsSlots {
+    double *base;   // this lane's column: base[slot * 64]
+    __device__ __forceinline__ double ld(int slot) const { return base[slot * 64]; }
+    __device__ __forceinline__ void st(int slot, double v) const { base[slot * 64] = v; }
+};
+// slot map: real system k (0..2): [k*(2LV+1) + 2l] = alpha_l, [+2l+1] = gamma_l, [+2LV] = 1/d
+//           complex system k:      CB + k*(4LV+2) + 4l + {0,1,2,3} = al.r, al.i, ga.r, ga.i; [+4LV, +4LV+1] = 1/d
+template <int LV> struct FSlots {
+    static constexpr int RS = 2 * LV + 1, CS = 4 * LV + 2, CB = 3 * RS, TOTAL = 3 * RS + 3 * CS;
+};
 
 struct cplx { double r, i; };
 __device__ __forceinline__ cplx cmul(cplx a, cplx b) { return {a.r * b.r - a.i * b.i, a.r * b.i + a.i * b.r}; }
 __device__ __forceinline__ cplx cinv(cplx a) { const double q = rcp(a.r * a.r + a.i * a.i); return {a.r * q, -a.i * q}; }
 
 template <bool ROW, int LV, int l>
-__device__ __forceinline__ void pcr_factor_real_level(const Lane &L, double &a, double &d, double &c, TriR<LV> &F)
+__device__ __forceinline__ void pcr_factor_real_level(const Lane &L, double &a, double &d, double &c, const LdsSlots &F, int s0)
 {
     constexpr int s = 1 << l;
     const bool vlo = L.z - s >= 0, vhi = L.z + s < L.n;
@@ -325,37 +340,37 @@ __device__ __forceinline__ void pcr_factor_real_level(const Lane &L, double &a, 
     d = d - al * (vlo ? c_lo : 0.0) - ga * (vhi ? a_hi : 0.0);
     a = vlo ? -al * a_lo : 0.0;
     c = vhi ? -ga * c_hi : 0.0;
-    F.al[l] = al; F.ga[l] = ga;
-    if constexpr (l + 1 < LV) pcr_factor_real_level<ROW, LV, l + 1>(L, a, d, c, F);
+    F.st(s0 + 2 * l, al); F.st(s0 + 2 * l + 1, ga);
+    if constexpr (l + 1 < LV) pcr_factor_real_level<ROW, LV, l + 1>(L, a, d, c, F, s0);
 }
 template <bool ROW, int LV>
-__device__ __forceinline__ void pcr_factor_real(const Lane &L, double a, double d, double c, TriR<LV> &F)
+__device__ __forceinline__ void pcr_factor_real(const Lane &L, double a, double d, double c, const LdsSlots &F, int s0)
 {
-    pcr_factor_real_level<ROW, LV, 0>(L, a, d, c, F);
-    F.invd = rcp(d);
+    pcr_factor_real_level<ROW, LV, 0>(L, a, d, c, F, s0);
+    F.st(s0 + 2 * LV, rcp(d));
 }
 
 template <bool ROW, int LV, int l>
-__device__ __forceinline__ void pcr_solve_real_level(const Lane &L, const TriR<LV> &F, double &b)
+__device__ __forceinline__ void pcr_solve_real_level(const Lane &L, const LdsSlots &F, int s0, double &b)
 {
     constexpr int s = 1 << l;
     const bool vlo = L.z - s >= 0, vhi = L.z + s < L.n;
     const double b_lo = from_lo<ROW, s>(b), b_hi = from_hi<ROW, s>(b);
-    b = b - F.al[l] * (vlo ? b_lo : 0.0) - F.ga[l] * (vhi ? b_hi : 0.0);
-    if constexpr (l + 1 < LV) pcr_solve_real_level<ROW, LV, l + 1>(L, F, b);
+    b = b - F.ld(s0 + 2 * l) * (vlo ? b_lo : 0.0) - F.ld(s0 + 2 * l + 1) * (vhi ? b_hi : 0.0);
+    if constexpr (l + 1 < LV) pcr_solve_real_level<ROW, LV, l + 1>(L, F, s0, b);
 }
 template <bool ROW, int LV>
-__device__ __forceinline__ double pcr_solve_real(const Lane &L, const TriR<LV> &F, double b)
+__device__ __forceinline__ double pcr_solve_real(const Lane &L, const LdsSlots &F, int s0, double b)
 {
-    pcr_solve_real_level<ROW, LV, 0>(L, F, b);
-    return b * F.invd;
+    pcr_solve_real_level<ROW, LV, 0>(L, F, s0, b);
+    return b * F.ld(s0 + 2 * LV);
 }
 
 template <bool ROW, int S> __device__ __forceinline__ cplx cfrom_lo(cplx a) { return {from_lo<ROW, S>(a.r), from_lo<ROW, S>(a.i)}; }
 template <bool ROW, int S> __device__ __forceinline__ cplx cfrom_hi(cplx a) { return {from_hi<ROW, S>(a.r), from_hi<ROW, S>(a.i)}; }
 
 template <bool ROW, int LV, int l>
-__device__ __forceinline__ void pcr_factor_cplx_level(const Lane &L, cplx &a, cplx &d, cplx &c, TriC<LV> &F)
+__device__ __forceinline__ void pcr_factor_cplx_level(const Lane &L, cplx &a, cplx &d, cplx &c, const LdsSlots &F, int s0)
 {
     constexpr int s = 1 << l;
     const cplx zero = {0.0, 0.0};
@@ -370,84 +385,83 @@ __device__ __forceinline__ void pcr_factor_cplx_level(const Lane &L, cplx &a, cp
     const cplx na = cmul(al, a_lo), nc = cmul(ga, c_hi);
     a = vlo ? cplx{-na.r, -na.i} : zero;
     c = vhi ? cplx{-nc.r, -nc.i} : zero;
-    F.alr[l] = al.r; F.ali[l] = al.i; F.gar[l] = ga.r; F.gai[l] = ga.i;
-    if constexpr (l + 1 < LV) pcr_factor_cplx_level<ROW, LV, l + 1>(L, a, d, c, F);
+    F.st(s0 + 4 * l, al.r); F.st(s0 + 4 * l + 1, al.i); F.st(s0 + 4 * l + 2, ga.r); F.st(s0 + 4 * l + 3, ga.i);
+    if constexpr (l + 1 < LV) pcr_factor_cplx_level<ROW, LV, l + 1>(L, a, d, c, F, s0);
 }
 template <bool ROW, int LV>
-__device__ __forceinline__ void pcr_factor_cplx(const Lane &L, double a0, cplx d, double c0, TriC<LV> &F)
+__device__ __forceinline__ void pcr_factor_cplx(const Lane &L, double a0, cplx d, double c0, const LdsSlots &F, int s0)
 {
     cplx a = {a0, 0.0}, c = {c0, 0.0};
-    pcr_factor_cplx_level<ROW, LV, 0>(L, a, d, c, F);
+    pcr_factor_cplx_level<ROW, LV, 0>(L, a, d, c, F, s0);
     const cplx inv = cinv(d);
-    F.invdr = inv.r; F.invdi = inv.i;
+    F.st(s0 + 4 * LV, inv.r); F.st(s0 + 4 * LV + 1, inv.i);
 }
 
 template <bool ROW, int LV, int l>
-__device__ __forceinline__ void pcr_solve_cplx_level(const Lane &L, const TriC<LV> &F, cplx &b)
+__device__ __forceinline__ void pcr_solve_cplx_level(const Lane &L, const LdsSlots &F, int s0, cplx &b)
 {
     constexpr int s = 1 << l;
     const cplx zero = {0.0, 0.0};
     const bool vlo = L.z - s >= 0, vhi = L.z + s < L.n;
     const cplx b_lo_r = cfrom_lo<ROW, s>(b), b_hi_r = cfrom_hi<ROW, s>(b);
     const cplx b_lo = vlo ? b_lo_r : zero, b_hi = vhi ? b_hi_r : zero;
-    const cplx t1 = cmul({F.alr[l], F.ali[l]}, b_lo), t2 = cmul({F.gar[l], F.gai[l]}, b_hi);
+    const cplx t1 = cmul({F.ld(s0 + 4 * l), F.ld(s0 + 4 * l + 1)}, b_lo);
+    const cplx t2 = cmul({F.ld(s0 + 4 * l + 2), F.ld(s0 + 4 * l + 3)}, b_hi);
     b = {b.r - t1.r - t2.r, b.i - t1.i - t2.i};
-    if constexpr (l + 1 < LV) pcr_solve_cplx_level<ROW, LV, l + 1>(L, F, b);
+    if constexpr (l + 1 < LV) pcr_solve_cplx_level<ROW, LV, l + 1>(L, F, s0, b);
 }
 template <bool ROW, int LV>
-__device__ __forceinline__ cplx pcr_solve_cplx(const Lane &L, const TriC<LV> &F, cplx b)
+__device__ __forceinline__ cplx pcr_solve_cplx(const Lane &L, const LdsSlots &F, int s0, cplx b)
 {
-    pcr_solve_cplx_level<ROW, LV, 0>(L, F, b);
-    return cmul(b, {F.invdr, F.invdi});
+    pcr_solve_cplx_level<ROW, LV, 0>(L, F, s0, b);
+    return cmul(b, {F.ld(s0 + 4 * LV), F.ld(s0 + 4 * LV + 1)});
 }
 
 // The six factored systems of one (h, J) pair: scipy's LU_real / LU_complex.
-template <int LV> struct Factors {
-    TriR<LV> rT, rP, rC;
-    TriC<LV> cT, cP, cC;
-};
-
 template <bool ROW, int LV>
-__device__ __forceinline__ void factorize(const Lane &L, const Jac &J, double h, Factors<LV> &F)
+__device__ __forceinline__ void factorize(const Lane &L, const Jac &J, double h, const LdsSlots &F)
 {
+    using S = FSlots<LV>;
     // radau.py:454-456: MU_REAL / h * I - J ; MU_COMPLEX / h * I - J
     const double ih = rcp(h);
     const double mr = rc::MU_REAL * ih, mcr = rc::MU_CR * ih, mci = rc::MU_CI * ih;
-    pcr_factor_real<ROW, LV>(L, -J.tt[0], mr - J.tt[1], -J.tt[2], F.rT);
-    pcr_factor_real<ROW, LV>(L, -J.pp[0], mr - J.pp[1], -J.pp[2], F.rP);
-    pcr_factor_real<ROW, LV>(L, -J.cc[0], mr - J.cc[1], -J.cc[2], F.rC);
-    pcr_factor_cplx<ROW, LV>(L, -J.tt[0], {mcr - J.tt[1], mci}, -J.tt[2], F.cT);
-    pcr_factor_cplx<ROW, LV>(L, -J.pp[0], {mcr - J.pp[1], mci}, -J.pp[2], F.cP);
-    pcr_factor_cplx<ROW, LV>(L, -J.cc[0], {mcr - J.cc[1], mci}, -J.cc[2], F.cC);
+    pcr_factor_real<ROW, LV>(L, -J.tt[0], mr - J.tt[1], -J.tt[2], F, 0 * S::RS);
+    pcr_factor_real<ROW, LV>(L, -J.pp[0], mr - J.pp[1], -J.pp[2], F, 1 * S::RS);
+    pcr_factor_real<ROW, LV>(L, -J.cc[0], mr - J.cc[1], -J.cc[2], F, 2 * S::RS);
+    pcr_factor_cplx<ROW, LV>(L, -J.tt[0], {mcr - J.tt[1], mci}, -J.tt[2], F, S::CB + 0 * S::CS);
+    pcr_factor_cplx<ROW, LV>(L, -J.pp[0], {mcr - J.pp[1], mci}, -J.pp[2], F, S::CB + 1 * S::CS);
+    pcr_factor_cplx<ROW, LV>(L, -J.cc[0], {mcr - J.cc[1], mci}, -J.cc[2], F, S::CB + 2 * S::CS);
 }
 
 // x = (mu_real/h I - J)^-1 b, in place, b indexed by species
 template <bool ROW, int LV>
-__device__ __forceinline__ void solve_real(const Lane &L, const Jac &J, const Factors<LV> &F, double b[3])
+__device__ __forceinline__ void solve_real(const Lane &L, const Jac &J, const LdsSlots &F, double b[3])
 {
-    const double xT = pcr_solve_real<ROW, LV>(L, F.rT, b[STT]);
+    using S = FSlots<LV>;
+    const double xT = pcr_solve_real<ROW, LV>(L, F, 0 * S::RS, b[STT]);
     const double xT_lo_r = from_lo<ROW, 1>(xT), xT_hi_r = from_hi<ROW, 1>(xT);
     const double xT_lo = L.has_lo ? xT_lo_r : 0.0, xT_hi = L.has_hi ? xT_hi_r : 0.0;
     const double bp = b[SPH] + (J.pt[0] * xT_lo + J.pt[1] * xT + J.pt[2] * xT_hi);
-    const double xP = pcr_solve_real<ROW, LV>(L, F.rP, bp);
+    const double xP = pcr_solve_real<ROW, LV>(L, F, 1 * S::RS, bp);
     const double bc = b[SCL] + (J.ct[0] * xT_lo + J.ct[1] * xT + J.ct[2] * xT_hi) + J.cp * xP;
-    const double xC = pcr_solve_real<ROW, LV>(L, F.rC, bc);
+    const double xC = pcr_solve_real<ROW, LV>(L, F, 2 * S::RS, bc);
     b[SPH] = xP; b[SCL] = xC; b[STT] = xT;
 }
 
 template <bool ROW, int LV>
-__device__ __forceinline__ void solve_cplx(const Lane &L, const Jac &J, const Factors<LV> &F, double br[3], double bi[3])
+__device__ __forceinline__ void solve_cplx(const Lane &L, const Jac &J, const LdsSlots &F, double br[3], double bi[3])
 {
+    using S = FSlots<LV>;
     const cplx zero = {0.0, 0.0};
-    const cplx xT = pcr_solve_cplx<ROW, LV>(L, F.cT, {br[STT], bi[STT]});
+    const cplx xT = pcr_solve_cplx<ROW, LV>(L, F, S::CB + 0 * S::CS, {br[STT], bi[STT]});
     const cplx xT_lo_r = cfrom_lo<ROW, 1>(xT), xT_hi_r = cfrom_hi<ROW, 1>(xT);
     const cplx xT_lo = L.has_lo ? xT_lo_r : zero, xT_hi = L.has_hi ? xT_hi_r : zero;
     const cplx bp = {br[SPH] + (J.pt[0] * xT_lo.r + J.pt[1] * xT.r + J.pt[2] * xT_hi.r),
                      bi[SPH] + (J.pt[0] * xT_lo.i + J.pt[1] * xT.i + J.pt[2] * xT_hi.i)};
-    const cplx xP = pcr_solve_cplx<ROW, LV>(L, F.cP, bp);
+    const cplx xP = pcr_solve_cplx<ROW, LV>(L, F, S::CB + 1 * S::CS, bp);
     const cplx bc = {br[SCL] + (J.ct[0] * xT_lo.r + J.ct[1] * xT.r + J.ct[2] * xT_hi.r) + J.cp * xP.r,
                      bi[SCL] + (J.ct[0] * xT_lo.i + J.ct[1] * xT.i + J.ct[2] * xT_hi.i) + J.cp * xP.i};
-    const cplx xC = pcr_solve_cplx<ROW, LV>(L, F.cC, bc);
+    const cplx xC = pcr_solve_cplx<ROW, LV>(L, F, S::CB + 2 * S::CS, bc);
     br[SPH] = xP.r; bi[SPH] = xP.i; br[SCL] = xC.r; bi[SCL] = xC.i; br[STT] = xT.r; bi[STT] = xT.i;
 }
 
@@ -644,7 +658,7 @@ enum Phase : int {
 
 struct SolverCounters { int nfev, njev, nlu, nsteps, nrej; };
 
-__device__ __forceinline__ bool lane_setup(int64_t N, int n, int R, Lane &L, int64_t &r)
+__device__ __forceinline__ bool lane_setup(int64_t r0, int64_t r1, int n, int R, Lane &L, int64_t &r)
 {
     const int lane = threadIdx.x & 63;
     const int seg = lane / n;
@@ -652,15 +666,15 @@ __device__ __forceinline__ bool lane_setup(int64_t N, int n, int R, Lane &L, int
     L.base = seg * n;
     L.has_lo = L.z > 0; L.has_hi = L.z < n - 1;
     L.segmask = ((n >= 64) ? ~0ull : ((1ull << n) - 1ull)) << L.base;
-    r = (int64_t)blockIdx.x * R + seg;
-    return (seg < R) && (r < N);
+    r = r0 + (int64_t)blockIdx.x * R + seg;
+    return (seg < R) && (r < r1);
 }
 
 template <int LV, bool ROW>
 __global__ __launch_bounds__(64) void step_kernel(const StepArgs a)
 {
     Lane L; int64_t r;
-    if (!lane_setup(a.N, a.n, a.R, L, r)) return;
+    if (!lane_setup(a.r0, a.r1, a.n, a.R, L, r)) return;
     const int64_t idx = r * a.n + L.z;
     uint32_t st = a.status[r];
     // a reactor whose last step raised stays frozen until the host rewrites its state
@@ -674,7 +688,8 @@ __global__ __launch_bounds__(64) void step_kernel(const StepArgs a)
     double aux[3] = {0, 0, 0};                        // y0 + h0 f0 (initial step) / error vector (refinement)
     double Q[3][3], y_old[3] = {0, 0, 0};             // dense output of the last accepted step
     Jac J;
-    Factors<LV> F;
+    __shared__ double lds_factors[FSlots<LV>::TOTAL * 64];
+    const LdsSlots F = {lds_factors + (threadIdx.x & 63)};
     double fac[3] = {0, 0, 0}; bool have_fac = false;
     double t_out = a.time[r];                         // ReactorState.time
     double t = 0, t_bound = 0, max_step = 0;
@@ -692,6 +707,8 @@ __global__ __launch_bounds__(64) void step_kernel(const StepArgs a)
     SolverCounters cnt = {0, 0, 0, 0, 0};
     int steps_left = a.n_steps;
     int phase = PH_OUTER_BEGIN;
+    long long diag_trips = 0, diag_newton = 0;
+    const long long clk0 = a.wave_diag ? __builtin_amdgcn_s_memtime() : 0, wall0 = a.wave_diag ? __builtin_amdgcn_s_memrealtime() : 0;
 
     while (true) {
         // ================= trips that need no RHS evaluation (run first so the lane can join this trip's evaluation)
@@ -795,6 +812,7 @@ __global__ __launch_bounds__(64) void step_kernel(const StepArgs a)
 
         // ================= this trip's evaluation points
         const bool newton = (phase == PH_NEWTON);
+        diag_trips++; if (__ballot(newton) != 0ull) diag_newton++;
         const bool skip_f0 = (phase == PH_OUTER_BEGIN) && f_valid;
         const bool eval1 = !skip_f0 && (phase == PH_OUTER_BEGIN || phase == PH_F1 || phase == PH_ERR_REFINE || phase == PH_FNEW || newton);
         double ye[3][3], Fe[3][3];
@@ -985,6 +1003,11 @@ __global__ __launch_bounds__(64) void step_kernel(const StepArgs a)
         }
     }
 
+    if (a.wave_diag && (threadIdx.x & 63) == 0) {
+        int64_t *o = a.wave_diag + (a.r0 / a.R + (int64_t)blockIdx.x) * 4;
+        o[0] = diag_trips; o[1] = diag_newton;
+        o[2] = __builtin_amdgcn_s_memtime() - clk0; o[3] = __builtin_amdgcn_s_memrealtime() - wall0;
+    }
     if (advanced) {
         a.pH[idx] = y0[SPH]; a.Cl[idx] = y0[SCL]; a.T[idx] = y0[STT];
         a.dH[idx] = dH; a.dRho[idx] = dR;
@@ -1017,7 +1040,7 @@ template <bool ROW>
 __global__ __launch_bounds__(64) void rhs_kernel(const RhsArgs a)
 {
     Lane L; int64_t r;
-    if (!lane_setup(a.N, a.n, a.R, L, r)) return;
+    if (!lane_setup(0, a.N, a.n, a.R, L, r)) return;
     const int64_t idx = r * a.n + L.z;
     RK k; load_reactor(a.par, a.bc, a.N, r, a.n, k);
     double y[3] = {a.pH[idx], a.Cl[idx], a.T[idx]}, f[3];
@@ -1034,7 +1057,7 @@ template <bool ROW>
 __global__ __launch_bounds__(64) void shuffle_selftest_kernel(const ShuffleTestArgs a)
 {
     Lane L; int64_t r;
-    if (!lane_setup(64 / a.n, a.n, 64 / a.n, L, r)) { a.out[threadIdx.x] = 0; return; }
+    if (!lane_setup(0, 64 / a.n, a.n, 64 / a.n, L, r)) { a.out[threadIdx.x] = 0; return; }
     const int lane = threadIdx.x & 63;
     const double x = 1000.0 * (lane + 1) + 0.5;
     int bad = 0;

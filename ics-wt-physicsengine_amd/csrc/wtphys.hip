@@ -46,8 +46,22 @@ struct wt_ensemble {
     double *dH = nullptr, *dRho = nullptr, *dK = nullptr;
     uint32_t *status = nullptr;
     int32_t *stats = nullptr;
+    int64_t *wave_diag = nullptr; // optional per-wavefront diagnostics (wt_ensemble_enable_wave_diag)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool have_bc = false, have_state = false;
+    // Launch schedule: the ensemble is cut into n_sub contiguous reactor ranges, each
+    // advanced on its own HIP stream in launches of at most chunk_steps outer steps.
+    // Reactors are independent, so the hardware queues interleave the ranges' wavefronts:
+    // a range whose launch ends in a slow wavefront only delays its own next launch, and
+    // 1250 wavefronts of work no longer take two full rounds on 1024 SIMDs.
+    int n_sub = 1, chunk_steps = 10;
+    hipStream_t sub_stream[WT_MAX_STREAMS] = {};
+    hipEvent_t sub_done[WT_MAX_STREAMS] = {};
+    hipEvent_t ev_fork = nullptr;
+    // optional per-launch HIP-event timing (bench.py roofline accounting)
+    bool time_launches = false;
+    std::vector<hipEvent_t> lt_pool;   // start/stop pairs
+    size_t lt_used = 0;
 };
 
 namespace {
@@ -55,36 +69,50 @@ namespace {
 wt::StepArgs make_args(const wt_ensemble *h, double dt, int n_steps)
 {
     wt::StepArgs a;
-    a.N = h->N; a.n = h->n; a.R = h->R;
+    a.N = h->N; a.r0 = 0; a.r1 = h->N; a.n = h->n; a.R = h->R;
     a.par = h->par; a.bc = h->bc;
     a.pH = h->pH; a.Cl = h->Cl; a.T = h->T; a.time = h->time; a.flow = h->flow;
     a.dH = h->dH; a.dRho = h->dRho; a.dK = h->dK;
-    a.status = h->status; a.stats = h->stats;
+    a.status = h->status; a.stats = h->stats; a.wave_diag = h->wave_diag;
     a.dt = dt; a.n_steps = n_steps;
     return a;
 }
 
 bool row_mode(int n) { return n == 2 || n == 4 || n == 8 || n == 16; }
 
-void launch_step(const wt_ensemble *h, const wt::StepArgs &a)
+void launch_step_raw(const wt_ensemble *h, const wt::StepArgs &a, hipStream_t stream);
+
+void launch_step(wt_ensemble *h, const wt::StepArgs &a, hipStream_t stream)
 {
-    const unsigned grid = (unsigned)((h->N + h->R - 1) / h->R);
+    if (!h->time_launches) { launch_step_raw(h, a, stream); return; }
+    if (h->lt_used + 2 > h->lt_pool.size()) {
+        for (int i = 0; i < 2; ++i) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) { launch_step_raw(h, a, stream); return; } h->lt_pool.push_back(e); }
+    }
+    (void)hipEventRecord(h->lt_pool[h->lt_used], stream);
+    launch_step_raw(h, a, stream);
+    (void)hipEventRecord(h->lt_pool[h->lt_used + 1], stream);
+    h->lt_used += 2;
+}
+
+void launch_step_raw(const wt_ensemble *h, const wt::StepArgs &a, hipStream_t stream)
+{
+    const unsigned grid = (unsigned)((a.r1 - a.r0 + h->R - 1) / h->R);
     const dim3 g(grid), b(64);
     const int lv = levels_for(h->n);
     if (row_mode(h->n)) { // n in {2,4,8,16}: every cross-lane move is a DPP row operation
         switch (lv) {
-        case 1: hipLaunchKernelGGL((wt::step_kernel<1, true>), g, b, 0, h->stream, a); break;
-        case 2: hipLaunchKernelGGL((wt::step_kernel<2, true>), g, b, 0, h->stream, a); break;
-        case 3: hipLaunchKernelGGL((wt::step_kernel<3, true>), g, b, 0, h->stream, a); break;
-        default: hipLaunchKernelGGL((wt::step_kernel<4, true>), g, b, 0, h->stream, a); break;
+        case 1: hipLaunchKernelGGL((wt::step_kernel<1, true>), g, b, 0, stream, a); break;
+        case 2: hipLaunchKernelGGL((wt::step_kernel<2, true>), g, b, 0, stream, a); break;
+        case 3: hipLaunchKernelGGL((wt::step_kernel<3, true>), g, b, 0, stream, a); break;
+        default: hipLaunchKernelGGL((wt::step_kernel<4, true>), g, b, 0, stream, a); break;
         }
     } else {
         switch (lv) {
-        case 2: hipLaunchKernelGGL((wt::step_kernel<2, false>), g, b, 0, h->stream, a); break;
-        case 3: hipLaunchKernelGGL((wt::step_kernel<3, false>), g, b, 0, h->stream, a); break;
-        case 4: hipLaunchKernelGGL((wt::step_kernel<4, false>), g, b, 0, h->stream, a); break;
-        case 5: hipLaunchKernelGGL((wt::step_kernel<5, false>), g, b, 0, h->stream, a); break;
-        default: hipLaunchKernelGGL((wt::step_kernel<6, false>), g, b, 0, h->stream, a); break;
+        case 2: hipLaunchKernelGGL((wt::step_kernel<2, false>), g, b, 0, stream, a); break;
+        case 3: hipLaunchKernelGGL((wt::step_kernel<3, false>), g, b, 0, stream, a); break;
+        case 4: hipLaunchKernelGGL((wt::step_kernel<4, false>), g, b, 0, stream, a); break;
+        case 5: hipLaunchKernelGGL((wt::step_kernel<5, false>), g, b, 0, stream, a); break;
+        default: hipLaunchKernelGGL((wt::step_kernel<6, false>), g, b, 0, stream, a); break;
         }
     }
 }
@@ -143,6 +171,13 @@ int wt_ensemble_create(int64_t n_reactors, int n_zones, int device, const double
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { cleanup(); return fail(WT_E_HIP, "hipStreamCreate failed"); }
     h->own_stream = true;
     if (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) { cleanup(); return fail(WT_E_HIP, "hipEventCreate failed"); }
+    if (hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess) { cleanup(); return fail(WT_E_HIP, "hipEventCreate failed"); }
+    {   // default schedule: up to 4 ranges, but keep at least 64 wavefronts per range
+        const int64_t waves = (n_reactors + h->R - 1) / h->R;
+        int ns = (int)(waves / 64);
+        h->n_sub = ns < 1 ? 1 : (ns > 4 ? 4 : ns);
+        h->chunk_steps = 10;
+    }
     hipError_t e = hipMemcpyAsync(h->par, par, sizeof(double) * WT_NP * N, hipMemcpyHostToDevice, h->stream);
     if (e == hipSuccess) e = hipMemsetAsync(h->status, 0, sizeof(uint32_t) * N, h->stream);
     if (e == hipSuccess) e = hipMemsetAsync(h->stats, 0, sizeof(int32_t) * 5 * N, h->stream);
@@ -159,8 +194,14 @@ int wt_ensemble_destroy(wt_ensemble *h)
     if (!h) return WT_OK;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    void *ptrs[] = {h->par, h->bc, h->pH, h->Cl, h->T, h->time, h->flow, h->dH, h->dRho, h->dK, h->status, h->stats};
+    void *ptrs[] = {h->par, h->bc, h->pH, h->Cl, h->T, h->time, h->flow, h->dH, h->dRho, h->dK, h->status, h->stats, h->wave_diag};
     for (void *p : ptrs) if (p) (void)hipFree(p);
+    for (int s = 0; s < WT_MAX_STREAMS; ++s) {
+        if (h->sub_stream[s]) { (void)hipStreamSynchronize(h->sub_stream[s]); (void)hipStreamDestroy(h->sub_stream[s]); }
+        if (h->sub_done[s]) (void)hipEventDestroy(h->sub_done[s]);
+    }
+    for (hipEvent_t e : h->lt_pool) (void)hipEventDestroy(e);
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
@@ -222,13 +263,73 @@ int wt_ensemble_step(wt_ensemble *h, double dt, int n_steps, int fused)
     if (n_steps < 0) return fail(WT_E_ARG, "n_steps must be >= 0");
     if (n_steps == 0) return WT_OK;
     HIP_TRY(hipSetDevice(h->device));
-    if (fused) {
-        launch_step(h, make_args(h, dt, n_steps));
-    } else {
-        const wt::StepArgs a = make_args(h, dt, 1);
-        for (int s = 0; s < n_steps; ++s) launch_step(h, a);
+    const int chunk = fused ? (h->chunk_steps > 0 ? h->chunk_steps : n_steps) : 1;
+    const int S = h->n_sub;
+    if (S <= 1) {
+        for (int done = 0; done < n_steps; done += chunk) {
+            launch_step(h, make_args(h, dt, (n_steps - done < chunk) ? n_steps - done : chunk), h->stream);
+        }
+        HIP_TRY(hipGetLastError());
+        return WT_OK;
+    }
+    for (int s = 0; s < S; ++s) {   // streams of the ranges are created on first use
+        if (!h->sub_stream[s]) {
+            HIP_TRY(hipStreamCreateWithFlags(&h->sub_stream[s], hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&h->sub_done[s], hipEventDisableTiming));
+        }
+    }
+    // fork: every range's stream waits for what is already queued on the handle's stream
+    HIP_TRY(hipEventRecord(h->ev_fork, h->stream));
+    for (int s = 0; s < S; ++s) HIP_TRY(hipStreamWaitEvent(h->sub_stream[s], h->ev_fork, 0));
+    const int64_t groups = (h->N + h->R - 1) / h->R;   // wavefront-sized groups of reactors
+    for (int done = 0; done < n_steps; done += chunk) {
+        wt::StepArgs a = make_args(h, dt, (n_steps - done < chunk) ? n_steps - done : chunk);
+        for (int s = 0; s < S; ++s) {
+            const int64_t g0 = groups * s / S, g1 = groups * (s + 1) / S;
+            a.r0 = g0 * h->R; a.r1 = (g1 * h->R < h->N) ? g1 * h->R : h->N;
+            if (a.r1 > a.r0) launch_step(h, a, h->sub_stream[s]);
+        }
     }
     HIP_TRY(hipGetLastError());
+    // join: later work on the handle's stream (copies, timers) sees every range finished
+    for (int s = 0; s < S; ++s) {
+        HIP_TRY(hipEventRecord(h->sub_done[s], h->sub_stream[s]));
+        HIP_TRY(hipStreamWaitEvent(h->stream, h->sub_done[s], 0));
+    }
+    return WT_OK;
+}
+
+int wt_ensemble_launch_timing(wt_ensemble *h, int enable)
+{
+    if (!h) return fail(WT_E_ARG, "NULL handle");
+    h->time_launches = enable != 0;
+    h->lt_used = 0;
+    return WT_OK;
+}
+
+int wt_ensemble_launch_stats(wt_ensemble *h, int64_t *n_launches, double *sum_ms, double *max_ms)
+{
+    if (!h || !n_launches || !sum_ms || !max_ms) return fail(WT_E_ARG, "NULL argument");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    double sum = 0.0, mx = 0.0;
+    for (size_t i = 0; i + 1 < h->lt_used; i += 2) {
+        float ms = 0.f;
+        HIP_TRY(hipEventSynchronize(h->lt_pool[i + 1]));
+        HIP_TRY(hipEventElapsedTime(&ms, h->lt_pool[i], h->lt_pool[i + 1]));
+        sum += ms; if (ms > mx) mx = ms;
+    }
+    *n_launches = (int64_t)(h->lt_used / 2); *sum_ms = sum; *max_ms = mx;
+    h->lt_used = 0;
+    return WT_OK;
+}
+
+int wt_ensemble_set_schedule(wt_ensemble *h, int n_streams, int chunk_steps)
+{
+    if (!h) return fail(WT_E_ARG, "NULL handle");
+    if (n_streams < 1 || n_streams > WT_MAX_STREAMS) return fail(WT_E_ARG, "n_streams out of range");
+    if (chunk_steps < 0) return fail(WT_E_ARG, "chunk_steps must be >= 0 (0 = whole call in one launch)");
+    h->n_sub = n_streams; h->chunk_steps = chunk_steps;
     return WT_OK;
 }
 
@@ -383,6 +484,26 @@ int wt_selftest_shuffles(int device, int n_zones, int *mismatches)
     int total = 0;
     for (int i = 0; i < 64; ++i) total += host[i];
     *mismatches = total;
+    return WT_OK;
+}
+
+int wt_ensemble_wave_diag(wt_ensemble *h, int64_t *out, int64_t capacity, int64_t *n_waves)
+{
+    if (!h || !n_waves) return fail(WT_E_ARG, "NULL argument");
+    HIP_TRY(hipSetDevice(h->device));
+    const int64_t nw = (h->N + h->R - 1) / h->R;
+    *n_waves = nw;
+    if (!h->wave_diag) {   // first call switches the diagnostics on
+        HIP_TRY(hipMalloc((void **)&h->wave_diag, sizeof(int64_t) * 4 * (size_t)nw));
+        HIP_TRY(hipMemsetAsync(h->wave_diag, 0, sizeof(int64_t) * 4 * (size_t)nw, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        return WT_OK;
+    }
+    if (out) {
+        if (capacity < nw) return fail(WT_E_ARG, "wave_diag buffer too small");
+        HIP_TRY(hipMemcpyAsync(out, h->wave_diag, sizeof(int64_t) * 4 * (size_t)nw, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+    }
     return WT_OK;
 }
 

@@ -29,6 +29,7 @@ extern "C" {
 
 #define WT_ABI_VERSION 1
 #define WT_MAX_ZONES 64 /* one reactor's zones live in one 64-lane wavefront */
+#define WT_MAX_STREAMS 8
 
 /* rows of the per-reactor constant block (values as the reference's __init__
  * computes them: reactor.py:229-270, chemistry.py:116-132, transport.py:202-290) */
@@ -92,10 +93,16 @@ int wt_ensemble_set_state(wt_ensemble *h, const double *pH, const double *Cl, co
 int wt_ensemble_set_boundary(wt_ensemble *h, const double *bc);
 
 /* IntegratedCSTR.step(dt, boundary) n_steps times (reactor.py:450-509), boundary
- * held constant; asynchronous on the handle's stream.  fused != 0 keeps the
- * state in registers across the n_steps outer steps of one launch; fused == 0
- * launches one kernel per outer step. */
+ * held constant; asynchronous, ordered after and before other work on the
+ * handle's stream.  fused != 0 keeps the state in registers across up to
+ * chunk_steps outer steps per launch; fused == 0 launches one kernel per outer
+ * step.  Results do not depend on the schedule (tests assert bitwise equality). */
 int wt_ensemble_step(wt_ensemble *h, double dt, int n_steps, int fused);
+/* Launch schedule: the ensemble is advanced as n_streams contiguous reactor ranges
+ * on internal HIP streams (fork/join around the handle's stream), at most
+ * chunk_steps outer steps per launch (0 = the whole call in one launch).
+ * Default: min(4, wavefronts/64) ranges, 10 steps. */
+int wt_ensemble_set_schedule(wt_ensemble *h, int n_streams, int chunk_steps);
 int wt_ensemble_synchronize(wt_ensemble *h);
 
 /* ReactorState read-back (reactor.py:113-147).  Any pointer may be NULL.
@@ -121,6 +128,13 @@ int wt_ensemble_export_state_device(wt_ensemble *h, void *dst_device);
 /* Use a caller-owned hipStream_t (e.g. torch's current stream) for all work. */
 int wt_ensemble_set_stream(wt_ensemble *h, void *hip_stream);
 
+/* Per-launch HIP-event timing (start/stop events around every step-kernel launch on
+ * the stream it is launched on).  launch_stats synchronises, returns the number of
+ * launches since timing was switched on / last read, the sum and the maximum of their
+ * durations, and resets the counters. */
+int wt_ensemble_launch_timing(wt_ensemble *h, int enable);
+int wt_ensemble_launch_stats(wt_ensemble *h, int64_t *n_launches, double *sum_ms, double *max_ms);
+
 /* HIP-event bracketing on the handle's stream, for benchmarks. */
 int wt_ensemble_timer_start(wt_ensemble *h);
 int wt_ensemble_timer_stop(wt_ensemble *h, float *elapsed_ms /* synchronises */);
@@ -128,6 +142,12 @@ int wt_ensemble_timer_stop(wt_ensemble *h, float *elapsed_ms /* synchronises */)
 /* Self-test of the kernel's cross-lane primitives (DPP row / wave shifts, segment
  * sums) against ds_bpermute for a given zone count; *mismatches must come back 0. */
 int wt_selftest_shuffles(int device, int n_zones, int *mismatches);
+
+/* Per-wavefront diagnostics of the LAST launch: {loop trips, trips with a Newton
+ * evaluation, shader clocks, 100 MHz wall ticks} per wavefront.  The first call
+ * allocates the buffer and switches recording on (out may be NULL); later calls
+ * copy [n_waves][4] int64 into `out`. */
+int wt_ensemble_wave_diag(wt_ensemble *h, int64_t *out, int64_t capacity, int64_t *n_waves);
 
 int64_t wt_ensemble_size(const wt_ensemble *h);
 int wt_ensemble_zones(const wt_ensemble *h);
