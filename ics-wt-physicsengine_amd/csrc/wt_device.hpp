@@ -121,6 +121,14 @@ template <bool ROW, int S> __device__ __forceinline__ double from_hi(double x)
     else return __shfl_down(x, S, 64);
 }
 
+// A value read from outside the segment only ever meets a zero coefficient, so it is
+// enough to make it FINITE: clearing the high dword (sign, exponent, top mantissa bits)
+// turns any NaN/Inf another reactor may hold into a denormal.  One v_cndmask per read.
+__device__ __forceinline__ double keep_if(bool valid, double x)
+{
+    return __hiloint2double(valid ? __double2hiint(x) : 0, __double2loint(x));
+}
+
 __device__ __forceinline__ bool seg_any(const Lane &L, bool p) { return (__ballot(p) & L.segmask) != 0ull; }
 __device__ __forceinline__ bool seg_all(const Lane &L, bool p) { return (__ballot(!p) & L.segmask) == 0ull; }
 
@@ -264,9 +272,9 @@ __device__ __forceinline__ void rhs_rows(const Lane &L, const RK &k, double H, d
     const double H_lo_r = from_lo<ROW, 1>(H), H_hi_r = from_hi<ROW, 1>(H);
     const double C_lo_r = from_lo<ROW, 1>(Cl), C_hi_r = from_hi<ROW, 1>(Cl);
     const double T_lo_r = from_lo<ROW, 1>(T), T_hi_r = from_hi<ROW, 1>(T);
-    const double H_lo = L.has_lo ? H_lo_r : 0.0, H_hi = L.has_hi ? H_hi_r : 0.0;
-    const double C_lo = L.has_lo ? C_lo_r : 0.0, C_hi = L.has_hi ? C_hi_r : 0.0;
-    const double T_lo = L.has_lo ? T_lo_r : 0.0, T_hi = L.has_hi ? T_hi_r : 0.0;
+    const double H_lo = keep_if(L.has_lo, H_lo_r), H_hi = keep_if(L.has_hi, H_hi_r);
+    const double C_lo = keep_if(L.has_lo, C_lo_r), C_hi = keep_if(L.has_hi, C_hi_r);
+    const double T_lo = keep_if(L.has_lo, T_lo_r), T_hi = keep_if(L.has_hi, T_hi_r);
     // K @ x with OpenBLAS' accumulation order: neighbours first, diagonal last
     const double mixH = (k_lo * H_lo + k_hi * H_hi) + kd * H;
     const double mixC = (k_lo * C_lo + k_hi * C_hi) + kd * Cl;
@@ -335,11 +343,13 @@ __device__ __forceinline__ void pcr_factor_real_level(const Lane &L, double &a, 
     const double d_lo = from_lo<ROW, s>(d), d_hi = from_hi<ROW, s>(d);
     const double a_lo = from_lo<ROW, s>(a), c_lo = from_lo<ROW, s>(c);
     const double a_hi = from_hi<ROW, s>(a), c_hi = from_hi<ROW, s>(c);
-    const double al = vlo ? a * rcp(d_lo) : 0.0;
-    const double ga = vhi ? c * rcp(d_hi) : 0.0;
-    d = d - al * (vlo ? c_lo : 0.0) - ga * (vhi ? a_hi : 0.0);
-    a = vlo ? -al * a_lo : 0.0;
-    c = vhi ? -ga * c_hi : 0.0;
+    // a == 0 where there is no lower neighbour (c likewise), so alpha/gamma vanish there by
+    // themselves once the foreign operands are finite
+    const double al = a * rcp(vlo ? d_lo : 1.0);
+    const double ga = c * rcp(vhi ? d_hi : 1.0);
+    d = d - al * keep_if(vlo, c_lo) - ga * keep_if(vhi, a_hi);
+    a = -al * keep_if(vlo, a_lo);
+    c = -ga * keep_if(vhi, c_hi);
     F.st(s0 + 2 * l, al); F.st(s0 + 2 * l + 1, ga);
     if constexpr (l + 1 < LV) pcr_factor_real_level<ROW, LV, l + 1>(L, a, d, c, F, s0);
 }
@@ -356,7 +366,7 @@ __device__ __forceinline__ void pcr_solve_real_level(const Lane &L, const LdsSlo
     constexpr int s = 1 << l;
     const bool vlo = L.z - s >= 0, vhi = L.z + s < L.n;
     const double b_lo = from_lo<ROW, s>(b), b_hi = from_hi<ROW, s>(b);
-    b = b - F.ld(s0 + 2 * l) * (vlo ? b_lo : 0.0) - F.ld(s0 + 2 * l + 1) * (vhi ? b_hi : 0.0);
+    b = b - F.ld(s0 + 2 * l) * keep_if(vlo, b_lo) - F.ld(s0 + 2 * l + 1) * keep_if(vhi, b_hi);
     if constexpr (l + 1 < LV) pcr_solve_real_level<ROW, LV, l + 1>(L, F, s0, b);
 }
 template <bool ROW, int LV>
@@ -373,18 +383,21 @@ template <bool ROW, int LV, int l>
 __device__ __forceinline__ void pcr_factor_cplx_level(const Lane &L, cplx &a, cplx &d, cplx &c, const LdsSlots &F, int s0)
 {
     constexpr int s = 1 << l;
-    const cplx zero = {0.0, 0.0};
     const bool vlo = L.z - s >= 0, vhi = L.z + s < L.n;
     const cplx d_lo = cfrom_lo<ROW, s>(d), d_hi = cfrom_hi<ROW, s>(d);
     const cplx a_lo = cfrom_lo<ROW, s>(a), c_lo = cfrom_lo<ROW, s>(c);
     const cplx a_hi = cfrom_hi<ROW, s>(a), c_hi = cfrom_hi<ROW, s>(c);
-    const cplx al = vlo ? cmul(a, cinv(d_lo)) : zero;
-    const cplx ga = vhi ? cmul(c, cinv(d_hi)) : zero;
-    const cplx t1 = cmul(al, vlo ? c_lo : zero), t2 = cmul(ga, vhi ? a_hi : zero);
+    const cplx dl = {vlo ? d_lo.r : 1.0, keep_if(vlo, d_lo.i)};
+    const cplx dh = {vhi ? d_hi.r : 1.0, keep_if(vhi, d_hi.i)};
+    const cplx al = cmul(a, cinv(dl));   // a == 0 without a lower neighbour => alpha == 0
+    const cplx ga = cmul(c, cinv(dh));
+    const cplx t1 = cmul(al, {keep_if(vlo, c_lo.r), keep_if(vlo, c_lo.i)});
+    const cplx t2 = cmul(ga, {keep_if(vhi, a_hi.r), keep_if(vhi, a_hi.i)});
     d = {d.r - t1.r - t2.r, d.i - t1.i - t2.i};
-    const cplx na = cmul(al, a_lo), nc = cmul(ga, c_hi);
-    a = vlo ? cplx{-na.r, -na.i} : zero;
-    c = vhi ? cplx{-nc.r, -nc.i} : zero;
+    const cplx na = cmul(al, {keep_if(vlo, a_lo.r), keep_if(vlo, a_lo.i)});
+    const cplx nc = cmul(ga, {keep_if(vhi, c_hi.r), keep_if(vhi, c_hi.i)});
+    a = {-na.r, -na.i};
+    c = {-nc.r, -nc.i};
     F.st(s0 + 4 * l, al.r); F.st(s0 + 4 * l + 1, al.i); F.st(s0 + 4 * l + 2, ga.r); F.st(s0 + 4 * l + 3, ga.i);
     if constexpr (l + 1 < LV) pcr_factor_cplx_level<ROW, LV, l + 1>(L, a, d, c, F, s0);
 }
@@ -401,10 +414,9 @@ template <bool ROW, int LV, int l>
 __device__ __forceinline__ void pcr_solve_cplx_level(const Lane &L, const LdsSlots &F, int s0, cplx &b)
 {
     constexpr int s = 1 << l;
-    const cplx zero = {0.0, 0.0};
     const bool vlo = L.z - s >= 0, vhi = L.z + s < L.n;
     const cplx b_lo_r = cfrom_lo<ROW, s>(b), b_hi_r = cfrom_hi<ROW, s>(b);
-    const cplx b_lo = vlo ? b_lo_r : zero, b_hi = vhi ? b_hi_r : zero;
+    const cplx b_lo = {keep_if(vlo, b_lo_r.r), keep_if(vlo, b_lo_r.i)}, b_hi = {keep_if(vhi, b_hi_r.r), keep_if(vhi, b_hi_r.i)};
     const cplx t1 = cmul({F.ld(s0 + 4 * l), F.ld(s0 + 4 * l + 1)}, b_lo);
     const cplx t2 = cmul({F.ld(s0 + 4 * l + 2), F.ld(s0 + 4 * l + 3)}, b_hi);
     b = {b.r - t1.r - t2.r, b.i - t1.i - t2.i};
@@ -440,7 +452,7 @@ __device__ __forceinline__ void solve_real(const Lane &L, const Jac &J, const Ld
     using S = FSlots<LV>;
     const double xT = pcr_solve_real<ROW, LV>(L, F, 0 * S::RS, b[STT]);
     const double xT_lo_r = from_lo<ROW, 1>(xT), xT_hi_r = from_hi<ROW, 1>(xT);
-    const double xT_lo = L.has_lo ? xT_lo_r : 0.0, xT_hi = L.has_hi ? xT_hi_r : 0.0;
+    const double xT_lo = keep_if(L.has_lo, xT_lo_r), xT_hi = keep_if(L.has_hi, xT_hi_r); // J.pt/ct[0,2] are 0 there
     const double bp = b[SPH] + (J.pt[0] * xT_lo + J.pt[1] * xT + J.pt[2] * xT_hi);
     const double xP = pcr_solve_real<ROW, LV>(L, F, 1 * S::RS, bp);
     const double bc = b[SCL] + (J.ct[0] * xT_lo + J.ct[1] * xT + J.ct[2] * xT_hi) + J.cp * xP;
@@ -452,10 +464,10 @@ template <bool ROW, int LV>
 __device__ __forceinline__ void solve_cplx(const Lane &L, const Jac &J, const LdsSlots &F, double br[3], double bi[3])
 {
     using S = FSlots<LV>;
-    const cplx zero = {0.0, 0.0};
     const cplx xT = pcr_solve_cplx<ROW, LV>(L, F, S::CB + 0 * S::CS, {br[STT], bi[STT]});
     const cplx xT_lo_r = cfrom_lo<ROW, 1>(xT), xT_hi_r = cfrom_hi<ROW, 1>(xT);
-    const cplx xT_lo = L.has_lo ? xT_lo_r : zero, xT_hi = L.has_hi ? xT_hi_r : zero;
+    const cplx xT_lo = {keep_if(L.has_lo, xT_lo_r.r), keep_if(L.has_lo, xT_lo_r.i)};
+    const cplx xT_hi = {keep_if(L.has_hi, xT_hi_r.r), keep_if(L.has_hi, xT_hi_r.i)};
     const cplx bp = {br[SPH] + (J.pt[0] * xT_lo.r + J.pt[1] * xT.r + J.pt[2] * xT_hi.r),
                      bi[SPH] + (J.pt[0] * xT_lo.i + J.pt[1] * xT.i + J.pt[2] * xT_hi.i)};
     const cplx xP = pcr_solve_cplx<ROW, LV>(L, F, S::CB + 1 * S::CS, bp);
@@ -706,8 +718,61 @@ __global__ __launch_bounds__(64) void step_kernel(const StepArgs a)
     double dH = 0, dR = 0, dK = 0; bool wrote_k = false, advanced = false;
     SolverCounters cnt = {0, 0, 0, 0, 0};
     int steps_left = a.n_steps;
+    bool pend_f = false;          // f(yc) of the last accepted step has not been evaluated yet
+    bool jac_after_fnew = false;  // that step also asked for a fresh Jacobian (radau.py:500,512)
     int phase = PH_OUTER_BEGIN;
     long long diag_trips = 0, diag_newton = 0;
+
+    // select_initial_step (common.py:68-134), order 3, up to the probe point y0 + h0 f0
+    auto initial_step_first_half = [&]() {
+        double sc[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) sc[q] = ATOL + fabs(yc[q]) * RTOL;
+        d0 = rms3<ROW>(L, yc, sc); d1 = rms3<ROW>(L, f, sc);
+        h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
+        h0 = fmin(h0, fabs(t_bound - t));
+#pragma unroll
+        for (int q = 0; q < 3; ++q) aux[q] = yc[q] + h0 * f[q];
+    };
+    // error_norm > 1: radau.py:489-496
+    auto reject_step = [&]() {
+        const double fct = predict_factor(h_abs_l, have_old_l, h_abs_old_l, error_norm, err_old_l);
+        h_abs_l *= fmax(MIN_FACTOR, safety * fct);
+        have_lu = false; rejected = true; cnt.nrej++;
+        phase = PH_ATTEMPT;
+    };
+    // step accepted: radau.py:500-539.  scipy evaluates f(y_new) right here; the value is first
+    // needed by the next error estimate, so unless a Jacobian refresh or the end of the outer
+    // step needs it at once, it is evaluated together with the next Newton trip (pend_f).
+    auto accept_step = [&]() {
+        const bool recompute_jac = (n_iter > 2) && have_rate && (rate > 1e-3);
+        double fct = predict_factor(h_abs_l, have_old_l, h_abs_old_l, error_norm, err_old_l);
+        fct = fmin(MAX_FACTOR, safety * fct);
+        if (!recompute_jac && fct < 1.2) fct = 1.0; else have_lu = false;
+        h_abs_old = h_abs;            // sic radau.py:520: the solver-level value
+        err_old = error_norm;
+        have_old = true;
+        h_abs = h_abs_l * fct;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const double z0 = rc::T00 * W[0][q] + rc::T01 * W[1][q] + rc::T02 * W[2][q];
+            const double z1 = rc::T10 * W[0][q] + rc::T11 * W[1][q] + rc::T12 * W[2][q];
+            const double z2 = W[0][q] + W[1][q];
+            y_old[q] = yc[q];
+            Q[q][0] = z0 * rc::P00 + z1 * rc::P10 + z2 * rc::P20;  // Q = Z^T P  radau.py:541-543
+            Q[q][1] = z0 * rc::P01 + z1 * rc::P11 + z2 * rc::P21;
+            Q[q][2] = z0 * rc::P02 + z1 * rc::P12 + z2 * rc::P22;
+            yc[q] = yc[q] + z2;
+        }
+        sol_t_old = t; sol_h = t_new - t; have_sol = true;
+        t = t_new;
+        cnt.nsteps++; cnt.nfev++;     // f(y_new) counted where scipy calls it
+        pend_f = true; f_valid = false;
+        current_jac = recompute_jac;
+        const bool more = (t - t_bound) < 0;
+        if (recompute_jac || !more) { jac_after_fnew = recompute_jac; phase = PH_FNEW; }
+        else phase = PH_STEP_BEGIN;
+    };
     const long long clk0 = a.wave_diag ? __builtin_amdgcn_s_memtime() : 0, wall0 = a.wave_diag ? __builtin_amdgcn_s_memrealtime() : 0;
 
     while (true) {
@@ -750,10 +815,14 @@ __global__ __launch_bounds__(64) void step_kernel(const StepArgs a)
 #pragma unroll
             for (int q = 0; q < 3; ++q) yc[q] = y0[q];
             have_fac = false; have_sol = false; have_old = false; have_lu = false; current_jac = true;
-            failed = false;
+            failed = false; pend_f = false;
             cnt = {0, 0, 0, 0, 0};
-            if (f_valid) {   // f(y0) is already in f: count it as scipy does and go on
+            if (f_valid) {
+                // f(y0) is already in f (last evaluation of the previous outer step, same y, same
+                // boundary): count it as scipy does and go straight to the initial-step probe
                 cnt.nfev++;
+                initial_step_first_half();
+                phase = PH_F1;
             }
         }
         if (phase == PH_STEP_BEGIN) {
@@ -813,8 +882,9 @@ __global__ __launch_bounds__(64) void step_kernel(const StepArgs a)
         // ================= this trip's evaluation points
         const bool newton = (phase == PH_NEWTON);
         diag_trips++; if (__ballot(newton) != 0ull) diag_newton++;
-        const bool skip_f0 = (phase == PH_OUTER_BEGIN) && f_valid;
-        const bool eval1 = !skip_f0 && (phase == PH_OUTER_BEGIN || phase == PH_F1 || phase == PH_ERR_REFINE || phase == PH_FNEW || newton);
+        const bool eval0 = (phase == PH_OUTER_BEGIN || phase == PH_F1 || phase == PH_ERR_REFINE || phase == PH_FNEW || newton);
+        // f(y) of a just-accepted step rides along with the next attempt's first Newton trip
+        const bool eval3 = newton && pend_f;
         double ye[3][3], Fe[3][3];
         // Z = T W (radau.py:124): Z[2] = W0 + W1
 #pragma unroll
@@ -822,38 +892,37 @@ __global__ __launch_bounds__(64) void step_kernel(const StepArgs a)
             const double z0 = rc::T00 * W[0][q] + rc::T01 * W[1][q] + rc::T02 * W[2][q];
             const double z1 = rc::T10 * W[0][q] + rc::T11 * W[1][q] + rc::T12 * W[2][q];
             const double z2 = W[0][q] + W[1][q];
-            double p0 = yc[q];                                        // PH_OUTER_BEGIN
+            double p0 = yc[q];                                        // PH_OUTER_BEGIN, PH_FNEW
             if (phase == PH_F1) p0 = aux[q];
             if (phase == PH_ERR_REFINE) p0 = yc[q] + aux[q];
-            if (phase == PH_FNEW) p0 = yc[q] + z2;
             if (newton) p0 = yc[q] + z0;
             ye[0][q] = p0; ye[1][q] = yc[q] + z1; ye[2][q] = yc[q] + z2;
         }
-        if (eval1) {
-            bad |= rhs_full<ROW>(L, k, ye[0], Fe[0]); cnt.nfev++;
+        if (eval0) {
+            bad |= rhs_full<ROW>(L, k, ye[0], Fe[0]);
+            if (phase != PH_FNEW) cnt.nfev++;
         }
         if (newton) {
             bad |= rhs_full<ROW>(L, k, ye[1], Fe[1]);
             bad |= rhs_full<ROW>(L, k, ye[2], Fe[2]);
             cnt.nfev += 2;
         }
+        if (__ballot(eval3) != 0ull) {
+            double fy[3];
+            const bool b3 = rhs_full<ROW>(L, k, yc, fy);
+            if (eval3) {
+                bad |= b3; pend_f = false;       // (counted in nfev when the step was accepted)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) f[q] = fy[q];
+            }
+        }
         if (seg_any(L, bad)) { bad = true; if (phase != PH_EXIT) phase = PH_OUTER_END; }
 
         // ================= per-phase epilogues
         if (phase == PH_OUTER_BEGIN) {
-            if (!skip_f0) {
 #pragma unroll
-                for (int q = 0; q < 3; ++q) f[q] = Fe[0][q];
-            }
-            // select_initial_step (common.py:68-134), order 3, first half
-            double sc[3];
-#pragma unroll
-            for (int q = 0; q < 3; ++q) sc[q] = ATOL + fabs(yc[q]) * RTOL;
-            d0 = rms3<ROW>(L, yc, sc); d1 = rms3<ROW>(L, f, sc);
-            h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
-            h0 = fmin(h0, fabs(t_bound - t));
-#pragma unroll
-            for (int q = 0; q < 3; ++q) aux[q] = yc[q] + h0 * f[q];
+            for (int q = 0; q < 3; ++q) f[q] = Fe[0][q];
+            initial_step_first_half();
             phase = PH_F1;
         } else if (phase == PH_F1) {
             double sc[3], df[3];
@@ -917,16 +986,15 @@ __global__ __launch_bounds__(64) void step_kernel(const StepArgs a)
                 else { need_jac = true; current_jac = true; have_lu = false; keep_h = true; phase = PH_ATTEMPT; }
             } else if (conv) {
                 // ---- error estimate radau.py:477-487
-                double y_new[3], err[3], esc[3];
+                double err[3], esc[3];
 #pragma unroll
                 for (int q = 0; q < 3; ++q) {
                     const double z0 = rc::T00 * W[0][q] + rc::T01 * W[1][q] + rc::T02 * W[2][q];
                     const double z1 = rc::T10 * W[0][q] + rc::T11 * W[1][q] + rc::T12 * W[2][q];
                     const double z2 = W[0][q] + W[1][q];
-                    y_new[q] = yc[q] + z2;
                     const double ZE = (z0 * rc::E0 + z1 * rc::E1 + z2 * rc::E2) / h;
                     err[q] = f[q] + ZE;
-                    esc[q] = ATOL + fmax(fabs(yc[q]), fabs(y_new[q])) * RTOL;
+                    esc[q] = ATOL + fmax(fabs(yc[q]), fabs(yc[q] + z2)) * RTOL;
                 }
                 solve_real<ROW, LV>(L, J, F, err);
                 error_norm = rms3<ROW>(L, err, esc);
@@ -936,12 +1004,9 @@ __global__ __launch_bounds__(64) void step_kernel(const StepArgs a)
                     for (int q = 0; q < 3; ++q) aux[q] = err[q];
                     phase = PH_ERR_REFINE;
                 } else if (error_norm > 1) {                                  // radau.py:489-496
-                    const double fct = predict_factor(h_abs_l, have_old_l, h_abs_old_l, error_norm, err_old_l);
-                    h_abs_l *= fmax(MIN_FACTOR, safety * fct);
-                    have_lu = false; rejected = true; cnt.nrej++;
-                    phase = PH_ATTEMPT;
+                    reject_step();
                 } else {
-                    phase = PH_FNEW;
+                    accept_step();
                 }
             }
         } else if (phase == PH_ERR_REFINE) {
@@ -957,40 +1022,15 @@ __global__ __launch_bounds__(64) void step_kernel(const StepArgs a)
             }
             solve_real<ROW, LV>(L, J, F, err);
             error_norm = rms3<ROW>(L, err, esc);
-            if (error_norm > 1) {
-                const double fct = predict_factor(h_abs_l, have_old_l, h_abs_old_l, error_norm, err_old_l);
-                h_abs_l *= fmax(MIN_FACTOR, safety * fct);
-                have_lu = false; rejected = true; cnt.nrej++;
-                phase = PH_ATTEMPT;
-            } else {
-                phase = PH_FNEW;
-            }
+            if (error_norm > 1) reject_step(); else accept_step();
         } else if (phase == PH_FNEW) {
-            // ---- accepted: radau.py:500-539
-            const bool recompute_jac = (n_iter > 2) && have_rate && (rate > 1e-3);
-            double fct = predict_factor(h_abs_l, have_old_l, h_abs_old_l, error_norm, err_old_l);
-            fct = fmin(MAX_FACTOR, safety * fct);
-            if (!recompute_jac && fct < 1.2) fct = 1.0; else have_lu = false;
-            h_abs_old = h_abs;            // sic radau.py:520: the solver-level value
-            err_old = error_norm;
-            have_old = true;
-            h_abs = h_abs_l * fct;
+            // f(y_new) of an accepted step that needs it before anything else can happen:
+            // Jacobian refresh (radau.py:512-514) or the end of the outer step
 #pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                const double z0 = rc::T00 * W[0][q] + rc::T01 * W[1][q] + rc::T02 * W[2][q];
-                const double z1 = rc::T10 * W[0][q] + rc::T11 * W[1][q] + rc::T12 * W[2][q];
-                const double z2 = W[0][q] + W[1][q];
-                y_old[q] = yc[q];
-                Q[q][0] = z0 * rc::P00 + z1 * rc::P10 + z2 * rc::P20;  // Q = Z^T P  radau.py:541-543
-                Q[q][1] = z0 * rc::P01 + z1 * rc::P11 + z2 * rc::P21;
-                Q[q][2] = z0 * rc::P02 + z1 * rc::P12 + z2 * rc::P22;
-                yc[q] = yc[q] + z2; f[q] = Fe[0][q];
-            }
-            sol_t_old = t; sol_h = t_new - t; have_sol = true;
-            t = t_new;
-            cnt.nsteps++;
+            for (int q = 0; q < 3; ++q) f[q] = Fe[0][q];
+            pend_f = false;
             f_valid = true;
-            if (recompute_jac) { need_jac = true; current_jac = true; } else current_jac = false;
+            if (jac_after_fnew) { need_jac = true; jac_after_fnew = false; }
             phase = ((t - t_bound) < 0) ? PH_STEP_BEGIN : PH_OUTER_END;
         }
 
