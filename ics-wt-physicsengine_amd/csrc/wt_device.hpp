@@ -98,9 +98,9 @@ struct Lane {
 
 template <int CTRL> __device__ __forceinline__ double dpp_mov(double x)
 {
-    int lo = __double2loint(x), hi = __double2hiint(x);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+    // bound_ctrl: lanes whose source lies outside the row / wavefront read 0; no "old" value to keep
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(x), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(x), CTRL, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
 
@@ -173,6 +173,14 @@ struct RK {
     // boundary-derived (reactor.py:336,349-368,385-395,426-443)
     double Qv, H_in, Cl_in, T_in, acid_dH, cl_dose, UAr, T_amb;
     bool has_acid, has_cl, has_heat;
+    // the same, pre-masked for this lane's zone so the RHS needs no per-term selects:
+    // inlet / dosing terms act on zone 0 only, the outlet sink on zone n-1 only
+    double Kex_hi;    // Kex if this zone has an upper neighbour else 0
+    double Qv_in;     // Qv in zone 0 else 0
+    double Qv_out;    // Qv in zone n-1 else 0
+    double acid0;     // acid dosing dH/dt in zone 0 (0 elsewhere / when off)
+    double dose0;     // chlorine dosing in zone 0 (0 elsewhere / when off)
+    double UAr_on;    // heat-loss coefficient (0 when off)
 };
 
 __device__ __forceinline__ void load_reactor(const double *par, const double *bc, int64_t N, int64_t r, int n, RK &k)
@@ -205,6 +213,16 @@ __device__ __forceinline__ void load_reactor(const double *par, const double *bc
     k.T_amb = B(8);
 }
 
+__device__ __forceinline__ void mask_reactor_for_lane(const Lane &L, RK &k)
+{
+    k.Kex_hi = L.has_hi ? k.Kex : 0.0;
+    k.Qv_in = L.has_lo ? 0.0 : k.Qv;
+    k.Qv_out = L.has_hi ? 0.0 : k.Qv;
+    k.acid0 = (!L.has_lo && k.has_acid) ? k.acid_dH : 0.0;
+    k.dose0 = (!L.has_lo && k.has_cl) ? k.cl_dose : 0.0;
+    k.UAr_on = k.has_heat ? k.UAr : 0.0;
+}
+
 // ---------------------------------------------------------------- zone-local properties
 struct PropPH { double H, iw, phi; bool bpos; }; // iw = 1/(beta*ln10)
 struct PropT { double kT, rho; bool bad; };
@@ -221,8 +239,8 @@ __device__ __forceinline__ PropPH prop_pH(const RK &k, double pH)
     const double iD = rcp(D);
     const double a0 = H2 * iD, a1 = (k.Ka1 * H) * iD, a2 = k.Ka1Ka2 * iD;
     const double beta = beta_w + k.cbeta * (a0 * a1 + 4 * a1 * a2 + a0 * a2);
-    p.bpos = beta > 0;                           // reactor.py:358,367,375 guards
-    p.iw = rcp(beta * rc::LN10);
+    p.bpos = beta > 0;                           // reactor.py:358,367,375 guards: no pH change unless beta > 0
+    p.iw = p.bpos ? rcp(beta * rc::LN10) : 0.0;
     const double iHK = rcp(H + k.KaH);
     p.phi = H * iHK + (k.KaH * iHK) * 0.02;
     p.H = H;
@@ -263,37 +281,26 @@ __device__ __forceinline__ void rhs_rows(const Lane &L, const RK &k, double H, d
     } else if (k.strat_mode == 2) {
         s = k.supp;
     }
-    const double k_hi = L.has_hi ? k.Kex * s : 0.0;      // K[i,i+1]  reactor.py:321-325
-    const double k_lo_r = from_lo<ROW, 1>(k_hi);
-    const double k_lo = L.has_lo ? k_lo_r : 0.0;          // K[i,i-1]
-    double kd = -(k_lo + k_hi);                           // reactor.py:329-332
-    if (!L.has_hi) kd -= k.Qv;                            // reactor.py:337
+    const double k_hi = k.Kex_hi * s;                     // K[i,i+1]  reactor.py:321-325 (0 above the top zone)
+    const double k_lo = keep_if(L.has_lo, from_lo<ROW, 1>(k_hi)); // K[i,i-1] (bound_ctrl gives 0 below zone 0 of lane 0)
+    const double kd = -(k_lo + k_hi) - k.Qv_out;          // reactor.py:329-337
 
-    const double H_lo_r = from_lo<ROW, 1>(H), H_hi_r = from_hi<ROW, 1>(H);
-    const double C_lo_r = from_lo<ROW, 1>(Cl), C_hi_r = from_hi<ROW, 1>(Cl);
-    const double T_lo_r = from_lo<ROW, 1>(T), T_hi_r = from_hi<ROW, 1>(T);
-    const double H_lo = keep_if(L.has_lo, H_lo_r), H_hi = keep_if(L.has_hi, H_hi_r);
-    const double C_lo = keep_if(L.has_lo, C_lo_r), C_hi = keep_if(L.has_hi, C_hi_r);
-    const double T_lo = keep_if(L.has_lo, T_lo_r), T_hi = keep_if(L.has_hi, T_hi_r);
-    // K @ x with OpenBLAS' accumulation order: neighbours first, diagonal last
+    const double H_lo = keep_if(L.has_lo, from_lo<ROW, 1>(H)), H_hi = keep_if(L.has_hi, from_hi<ROW, 1>(H));
+    const double C_lo = keep_if(L.has_lo, from_lo<ROW, 1>(Cl)), C_hi = keep_if(L.has_hi, from_hi<ROW, 1>(Cl));
+    const double T_lo = keep_if(L.has_lo, from_lo<ROW, 1>(T)), T_hi = keep_if(L.has_hi, from_hi<ROW, 1>(T));
+    // K @ x with OpenBLAS' accumulation order: neighbours first, diagonal last.  k_lo / k_hi are
+    // exactly 0 where there is no neighbour, and what was read there is finite (keep_if).
     const double mixH = (k_lo * H_lo + k_hi * H_hi) + kd * H;
     const double mixC = (k_lo * C_lo + k_hi * C_hi) + kd * Cl;
     const double mixT = (k_lo * T_lo + k_hi * T_hi) + kd * T;
 
-    double dpH = 0.0, dCl = 0.0, dT = 0.0;
-    if (!L.has_lo) { // zone 0: dosing and inlet terms (reactor.py:349-368,388-395,420)
-        if (k.has_acid && bpos) dpH += (-k.acid_dH) * iw;
-        const double dH_in = k.Qv * (k.H_in - H);
-        if (bpos) dpH += (-dH_in) * iw;
-        if (k.has_cl) dCl += k.cl_dose;
-        dCl += k.Qv * (k.Cl_in - Cl);
-        dT += k.Qv * (k.T_in - T);
-    }
-    if (bpos) dpH += (-mixH) * iw;                        // reactor.py:371-376
-    dCl += mixC;                                          // reactor.py:398
-    dCl -= kphi * Cl;                                     // reactor.py:401-411
-    dT += mixT;                                           // reactor.py:423
-    if (k.has_heat) dT -= k.UAr * (T - k.T_amb);          // reactor.py:426-443
+    // zone-0 dosing and inlet (reactor.py:349-368,388-395,420) through pre-masked coefficients;
+    // iw is 0 when the reference's `beta > 0` guard fails
+    const double dpH = -((k.acid0 + k.Qv_in * (k.H_in - H)) + mixH) * iw;            // reactor.py:349-376
+    double dCl = (k.dose0 + k.Qv_in * (k.Cl_in - Cl)) + mixC;                        // reactor.py:385-398
+    dCl -= kphi * Cl;                                                                 // reactor.py:401-411
+    const double dT = (k.Qv_in * (k.T_in - T) + mixT) - k.UAr_on * (T - k.T_amb);    // reactor.py:420-443
+    (void)bpos;
     f[SPH] = dpH; f[SCL] = dCl; f[STT] = dT;
 }
 
@@ -691,7 +698,7 @@ __global__ __launch_bounds__(64) void step_kernel(const StepArgs a)
     uint32_t st = a.status[r];
     // a reactor whose last step raised stays frozen until the host rewrites its state
     if (st & (ST_T_RANGE | ST_T_RANGE_POST)) return;
-    RK k; load_reactor(a.par, a.bc, a.N, r, a.n, k);
+    RK k; load_reactor(a.par, a.bc, a.N, r, a.n, k); mask_reactor_for_lane(L, k);
 
     // ---- per-reactor state (segment-uniform scalars are replicated in every lane)
     double y0[3] = {a.pH[idx], a.Cl[idx], a.T[idx]}; // state at the start of the outer step
@@ -1082,7 +1089,7 @@ __global__ __launch_bounds__(64) void rhs_kernel(const RhsArgs a)
     Lane L; int64_t r;
     if (!lane_setup(0, a.N, a.n, a.R, L, r)) return;
     const int64_t idx = r * a.n + L.z;
-    RK k; load_reactor(a.par, a.bc, a.N, r, a.n, k);
+    RK k; load_reactor(a.par, a.bc, a.N, r, a.n, k); mask_reactor_for_lane(L, k);
     double y[3] = {a.pH[idx], a.Cl[idx], a.T[idx]}, f[3];
     const bool bad = rhs_full<ROW>(L, k, y, f);
     a.dpH[idx] = f[SPH]; a.dCl[idx] = f[SCL]; a.dT[idx] = f[STT];

@@ -8,6 +8,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 10000
 cols, bc = wt.make_ensemble(N)
 ens = wt.ReactorEnsemble(cols, n_zones=n); ens.set_boundary(bc)
+ens.set_schedule(1, 0)  # one range, one launch per call: the diagnostics cover the whole call
 ens.step(1.0, n_steps=100, fused=True, download=False); ens.synchronize()
 ens.wave_diag()
 for label, k, fused in (("stepwise", 1, False), ("stepwise", 1, False), ("fused50", 50, True)):
