@@ -331,8 +331,9 @@ class ReactorEnsemble:
         return out[0], out[1], out[2], fl
 
     def wave_diag(self) -> Optional[np.ndarray]:
-        """Per-wavefront diagnostics of the last launch, (n_waves, 4) int64:
-        loop trips, Newton trips, shader clocks, 100 MHz wall ticks.  The first
+        """Per-wavefront diagnostics of the last launch, (n_waves, 8) int64:
+        loop trips, Newton trips, shader clocks, 100 MHz wall ticks, factorize / num_jac /
+        deferred-f block executions, spare.  The first
         call only switches recording on and returns None."""
         nw = C.c_int64(0)
         L = _native.lib()
@@ -341,7 +342,7 @@ class ReactorEnsemble:
             self._diag_on = True
             return None
         _native.check(L.wt_ensemble_wave_diag(self._h, None, 0, C.byref(nw)))
-        out = np.zeros((nw.value, 4), dtype=np.int64)
+        out = np.zeros((nw.value, 8), dtype=np.int64)
         _native.check(L.wt_ensemble_wave_diag(self._h, out.ctypes.data_as(C.POINTER(C.c_int64)), nw.value, C.byref(nw)))
         return out
 

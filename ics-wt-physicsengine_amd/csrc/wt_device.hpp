@@ -83,7 +83,8 @@ struct StepArgs {
     double *dH, *dRho, *dK; // derived [N][n]
     uint32_t *status;    // [N]
     int32_t *stats;      // [N][5] or nullptr
-    int64_t *wave_diag;  // [n_waves][4] or nullptr: trips, Newton trips, shader clocks, wall clock (100 MHz)
+    int64_t *wave_diag;  // [n_waves][8] or nullptr: trips, Newton trips, shader clocks, wall clock (100 MHz),
+                         //                          factorize / num_jac / deferred-f block executions, spare
     double dt;
     int n_steps;
 };
@@ -161,6 +162,20 @@ __device__ __forceinline__ double rcp(double x)
     r = __builtin_fma(r, e, r);
     e = __builtin_fma(-x, r, 1.0);
     return __builtin_fma(r, e, r);
+}
+
+// x^(1/4) and x^(-1/4) for the step-size controller (radau.py:171-174, common.py:130)
+// through two square roots instead of the general pow(); the result only steers h.
+__device__ __forceinline__ double root4(double x) { return sqrt(sqrt(x)); }
+
+// rate ** k for k = 1..6 (radau.py:113) by repeated multiplication
+__device__ __forceinline__ double powi6(double x, int k)
+{
+    const double x2 = x * x, x3 = x2 * x;
+    double r = x;
+    r = (k == 2) ? x2 : r; r = (k == 3) ? x3 : r; r = (k == 4) ? x2 * x2 : r;
+    r = (k == 5) ? x2 * x3 : r; r = (k == 6) ? x3 * x3 : r;
+    return r;
 }
 
 // ---------------------------------------------------------------- reactor constants
@@ -658,8 +673,9 @@ __device__ __forceinline__ double predict_factor(double h_abs, bool have_old, do
                                                  double error_norm, double error_norm_old)
 {
     double mult = 1.0;
-    if (have_old && error_norm != 0) mult = h_abs / h_abs_old * pow(error_norm_old / error_norm, 0.25);
-    return fmin(1.0, mult) * pow(error_norm, -0.25);
+    const double ie = rcp(error_norm);           // +inf for error_norm == 0, as numpy's 0 ** -0.25
+    if (have_old && error_norm != 0) mult = h_abs * rcp(h_abs_old) * root4(error_norm_old * ie);
+    return fmin(1.0, mult) * root4(ie);
 }
 
 // ---------------------------------------------------------------- the solver state machine
@@ -728,7 +744,7 @@ __global__ __launch_bounds__(64) void step_kernel(const StepArgs a)
     bool pend_f = false;          // f(yc) of the last accepted step has not been evaluated yet
     bool jac_after_fnew = false;  // that step also asked for a fresh Jacobian (radau.py:500,512)
     int phase = PH_OUTER_BEGIN;
-    long long diag_trips = 0, diag_newton = 0;
+    long long diag_trips = 0, diag_newton = 0, diag_fact = 0, diag_jac = 0, diag_f3 = 0;
 
     // select_initial_step (common.py:68-134), order 3, up to the probe point y0 + h0 f0
     auto initial_step_first_half = [&]() {
@@ -736,7 +752,7 @@ __global__ __launch_bounds__(64) void step_kernel(const StepArgs a)
 #pragma unroll
         for (int q = 0; q < 3; ++q) sc[q] = ATOL + fabs(yc[q]) * RTOL;
         d0 = rms3<ROW>(L, yc, sc); d1 = rms3<ROW>(L, f, sc);
-        h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
+        h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 * rcp(d1);
         h0 = fmin(h0, fabs(t_bound - t));
 #pragma unroll
         for (int q = 0; q < 3; ++q) aux[q] = yc[q] + h0 * f[q];
@@ -861,7 +877,7 @@ __global__ __launch_bounds__(64) void step_kernel(const StepArgs a)
 #pragma unroll
                         for (int q = 0; q < 3; ++q) Z0[s][q] = 0.0;
                 } else {
-                    const double isol = 1.0 / sol_h;
+                    const double isol = rcp(sol_h);
                     const double cs[3] = {rc::C0, rc::C1, 1.0};
 #pragma unroll
                     for (int s = 0; s < 3; ++s) {
@@ -882,9 +898,11 @@ __global__ __launch_bounds__(64) void step_kernel(const StepArgs a)
                 phase = PH_NEWTON;
             }
         }
+        if (__ballot(phase == PH_NEWTON && !have_lu) != 0ull) diag_fact++;
         if (phase == PH_NEWTON && !have_lu) {
             factorize<ROW, LV>(L, J, h, F); have_lu = true; cnt.nlu += 2;      // radau.py:454-456
         }
+
 
         // ================= this trip's evaluation points
         const bool newton = (phase == PH_NEWTON);
@@ -915,6 +933,7 @@ __global__ __launch_bounds__(64) void step_kernel(const StepArgs a)
             cnt.nfev += 2;
         }
         if (__ballot(eval3) != 0ull) {
+            diag_f3++;
             double fy[3];
             const bool b3 = rhs_full<ROW>(L, k, yc, fy);
             if (eval3) {
@@ -935,10 +954,10 @@ __global__ __launch_bounds__(64) void step_kernel(const StepArgs a)
             double sc[3], df[3];
 #pragma unroll
             for (int q = 0; q < 3; ++q) { sc[q] = ATOL + fabs(yc[q]) * RTOL; df[q] = Fe[0][q] - f[q]; }
-            const double d2 = rms3<ROW>(L, df, sc) / h0;
+            const double d2 = rms3<ROW>(L, df, sc) * rcp(h0);
             double h1;
             if (d1 <= 1e-15 && d2 <= 1e-15) h1 = fmax(1e-6, h0 * 1e-3);
-            else h1 = pow(0.01 / fmax(d1, d2), 0.25);
+            else h1 = root4(0.01 * rcp(fmax(d1, d2)));
             h_abs = fmin(fmin(100 * h0, h1), fmin(fabs(t_bound - t), max_step));
             need_jac = true;                                          // radau.py:359-365
             phase = PH_STEP_BEGIN;
@@ -953,7 +972,7 @@ __global__ __launch_bounds__(64) void step_kernel(const StepArgs a)
             if (!seg_all(L, finite)) {
                 diverged = true;
             } else {
-                const double ih = 1.0 / h;
+                const double ih = rcp(h);
                 const double M_real = rc::MU_REAL * ih, Mcr = rc::MU_CR * ih, Mci = rc::MU_CI * ih;
                 double fr[3], fcr[3], fci[3], scale[3];
 #pragma unroll
@@ -975,13 +994,14 @@ __global__ __launch_bounds__(64) void step_kernel(const StepArgs a)
                     ssum += u * u + v * v + w * w;
                 }
                 const double dW_norm = sqrt(seg_sum<ROW>(L, ssum) / (double)(9 * L.n));
-                if (have_norm_old) { rate = dW_norm / dW_norm_old; have_rate = true; }
-                if (have_rate && (rate >= 1 || pow(rate, (double)(NEWTON_MAXITER - kk)) / (1 - rate) * dW_norm > rc::NEWTON_TOL)) {
+                if (have_norm_old) { rate = dW_norm * rcp(dW_norm_old); have_rate = true; }
+                const double i1r = rcp(1 - rate);
+                if (have_rate && (rate >= 1 || powi6(rate, NEWTON_MAXITER - kk) * i1r * dW_norm > rc::NEWTON_TOL)) {
                     diverged = true;
                 } else {
 #pragma unroll
                     for (int q = 0; q < 3; ++q) { W[0][q] += fr[q]; W[1][q] += fcr[q]; W[2][q] += fci[q]; }
-                    if (dW_norm == 0 || (have_rate && rate / (1 - rate) * dW_norm < rc::NEWTON_TOL)) conv = true;
+                    if (dW_norm == 0 || (have_rate && rate * i1r * dW_norm < rc::NEWTON_TOL)) conv = true;
                     dW_norm_old = dW_norm; have_norm_old = true;
                 }
             }
@@ -994,12 +1014,13 @@ __global__ __launch_bounds__(64) void step_kernel(const StepArgs a)
             } else if (conv) {
                 // ---- error estimate radau.py:477-487
                 double err[3], esc[3];
+                const double ih_e = rcp(h);
 #pragma unroll
                 for (int q = 0; q < 3; ++q) {
                     const double z0 = rc::T00 * W[0][q] + rc::T01 * W[1][q] + rc::T02 * W[2][q];
                     const double z1 = rc::T10 * W[0][q] + rc::T11 * W[1][q] + rc::T12 * W[2][q];
                     const double z2 = W[0][q] + W[1][q];
-                    const double ZE = (z0 * rc::E0 + z1 * rc::E1 + z2 * rc::E2) / h;
+                    const double ZE = (z0 * rc::E0 + z1 * rc::E1 + z2 * rc::E2) * ih_e;
                     err[q] = f[q] + ZE;
                     esc[q] = ATOL + fmax(fabs(yc[q]), fabs(yc[q] + z2)) * RTOL;
                 }
@@ -1018,12 +1039,13 @@ __global__ __launch_bounds__(64) void step_kernel(const StepArgs a)
             }
         } else if (phase == PH_ERR_REFINE) {
             double err[3], esc[3];
+            const double ih_e = rcp(h);
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
                 const double z0 = rc::T00 * W[0][q] + rc::T01 * W[1][q] + rc::T02 * W[2][q];
                 const double z1 = rc::T10 * W[0][q] + rc::T11 * W[1][q] + rc::T12 * W[2][q];
                 const double z2 = W[0][q] + W[1][q];
-                const double ZE = (z0 * rc::E0 + z1 * rc::E1 + z2 * rc::E2) / h;
+                const double ZE = (z0 * rc::E0 + z1 * rc::E1 + z2 * rc::E2) * ih_e;
                 err[q] = Fe[0][q] + ZE;
                 esc[q] = ATOL + fmax(fabs(yc[q]), fabs(yc[q] + z2)) * RTOL;
             }
@@ -1042,6 +1064,7 @@ __global__ __launch_bounds__(64) void step_kernel(const StepArgs a)
         }
 
         // ================= finite-difference Jacobian at (yc, f) when a phase asked for it
+        if (__ballot(need_jac) != 0ull) diag_jac++;
         if (need_jac) {
             bool jbad = false;
             num_jac<ROW>(L, k, yc, f, fac, have_fac, J, jbad); cnt.njev++;
@@ -1051,8 +1074,8 @@ __global__ __launch_bounds__(64) void step_kernel(const StepArgs a)
     }
 
     if (a.wave_diag && (threadIdx.x & 63) == 0) {
-        int64_t *o = a.wave_diag + (a.r0 / a.R + (int64_t)blockIdx.x) * 4;
-        o[0] = diag_trips; o[1] = diag_newton;
+        int64_t *o = a.wave_diag + (a.r0 / a.R + (int64_t)blockIdx.x) * 8;
+        o[0] = diag_trips; o[1] = diag_newton; o[4] = diag_fact; o[5] = diag_jac; o[6] = diag_f3; o[7] = 0;
         o[2] = __builtin_amdgcn_s_memtime() - clk0; o[3] = __builtin_amdgcn_s_memrealtime() - wall0;
     }
     if (advanced) {

@@ -144,9 +144,10 @@ int wt_ensemble_timer_stop(wt_ensemble *h, float *elapsed_ms /* synchronises */)
 int wt_selftest_shuffles(int device, int n_zones, int *mismatches);
 
 /* Per-wavefront diagnostics of the LAST launch: {loop trips, trips with a Newton
- * evaluation, shader clocks, 100 MHz wall ticks} per wavefront.  The first call
- * allocates the buffer and switches recording on (out may be NULL); later calls
- * copy [n_waves][4] int64 into `out`. */
+ * evaluation, shader clocks, 100 MHz wall ticks, factorisation / Jacobian /
+ * deferred-f block executions, spare} per wavefront.  The first call allocates the
+ * buffer and switches recording on (out may be NULL); later calls copy
+ * [n_waves][8] int64 into `out`. */
 int wt_ensemble_wave_diag(wt_ensemble *h, int64_t *out, int64_t capacity, int64_t *n_waves);
 
 int64_t wt_ensemble_size(const wt_ensemble *h);

@@ -18,6 +18,7 @@ for label, k, fused in (("stepwise", 1, False), ("stepwise", 1, False), ("fused5
     clk = d[:, 2] / k; wall = d[:, 3] / 100.0 / k  # us
     print(f"{label}: launch {ms*1e3/k:.1f} us/step | trips/step mean {d[:,0].mean()/k:.1f} max {d[:,0].max()/k:.1f} | newton trips mean {d[:,1].mean()/k:.1f}"
           f" | wave us/step mean {wall.mean():.1f} p50 {np.median(wall):.1f} p90 {np.percentile(wall,90):.1f} p99 {np.percentile(wall,99):.1f} max {wall.max():.1f}"
+          f" | fact {d[:,4].mean()/k:.2f} jac {d[:,5].mean()/k:.2f} f3 {d[:,6].mean()/k:.2f}"
           f" | clk/wall GHz {np.mean(clk/wall)/1e3:.2f} | reactor nfev mean {st[:,0].mean():.1f} max {st[:,0].max()}")
     if k == 1:
         srt = np.sort(wall)[::-1][:8]; print("   slowest waves us:", np.round(srt, 1), "trips:", np.sort(d[:, 0])[::-1][:8])
