@@ -80,7 +80,7 @@ def main() -> int:
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--reactors", type=int, default=10000, help="reactors per GPU")
     ap.add_argument("--zones", type=int, default=8)
-    ap.add_argument("--chunk", type=int, default=10,
+    ap.add_argument("--chunk", type=int, default=25,
                     help="outer steps per kernel launch (1 = one launch per outer step)")
     ap.add_argument("--streams", type=int, default=0,
                     help="reactor ranges / HIP streams per GPU (0 = library default: min(4, wavefronts/64))")
@@ -120,7 +120,7 @@ def main() -> int:
         if world > 1:
             dist.barrier()
 
-    if args.streams > 0 or args.chunk != 10:
+    if args.streams > 0 or args.chunk != 25:
         waves = -(-N // (64 // n))
         ens.set_schedule(args.streams if args.streams > 0 else max(1, min(4, waves // 64)), max(1, args.chunk))
     n_streams = args.streams if args.streams > 0 else max(1, min(4, (-(-N // (64 // n))) // 64))

@@ -276,10 +276,13 @@ class ReactorEnsemble:
             raise
         return self.state if download else None
 
-    def set_schedule(self, n_streams: int, chunk_steps: int = 10) -> None:
+    def set_schedule(self, n_streams: int, chunk_steps: int = 25) -> None:
         """Advance the ensemble as ``n_streams`` contiguous reactor ranges on internal HIP
         streams, at most ``chunk_steps`` outer steps per launch (0 = one launch per call)."""
         _native.check(_native.lib().wt_ensemble_set_schedule(self._h, int(n_streams), int(chunk_steps)))
+
+    def set_sync(self, sync_outer: bool) -> None:
+        _native.check(_native.lib().wt_ensemble_set_sync(self._h, 1 if sync_outer else 0))
 
     def launch_timing(self, enable: bool = True) -> None:
         _native.check(_native.lib().wt_ensemble_launch_timing(self._h, 1 if enable else 0))

@@ -87,6 +87,7 @@ struct StepArgs {
                          //                          factorize / num_jac / deferred-f block executions, spare
     double dt;
     int n_steps;
+    int sync_outer;   // 1: the reactors of a wavefront start every outer step together
 };
 
 // ---------------------------------------------------------------- lane geometry and cross-lane moves
@@ -800,7 +801,10 @@ __global__ __launch_bounds__(64) void step_kernel(const StepArgs a)
 
     while (true) {
         // ================= trips that need no RHS evaluation (run first so the lane can join this trip's evaluation)
-        if (phase == PH_OUTER_END) {
+        // Optional rendez-vous: reactors that finished their outer step wait until every reactor of the
+        // wavefront has, so Jacobians, factorisations and Newton trips of the next step coincide again.
+        const bool hold_outer = a.sync_outer && (__ballot(phase != PH_OUTER_END && phase != PH_EXIT) != 0ull);
+        if (phase == PH_OUTER_END && !hold_outer) {
             if (bad) {
                 st |= ST_T_RANGE;                      // the reference raised: self.state untouched
                 phase = PH_EXIT;

@@ -54,7 +54,8 @@ struct wt_ensemble {
     // Reactors are independent, so the hardware queues interleave the ranges' wavefronts:
     // a range whose launch ends in a slow wavefront only delays its own next launch, and
     // 1250 wavefronts of work no longer take two full rounds on 1024 SIMDs.
-    int n_sub = 1, chunk_steps = 10;
+    int n_sub = 1, chunk_steps = 25;
+    int sync_outer = 1;
     hipStream_t sub_stream[WT_MAX_STREAMS] = {};
     hipEvent_t sub_done[WT_MAX_STREAMS] = {};
     hipEvent_t ev_fork = nullptr;
@@ -74,7 +75,7 @@ wt::StepArgs make_args(const wt_ensemble *h, double dt, int n_steps)
     a.pH = h->pH; a.Cl = h->Cl; a.T = h->T; a.time = h->time; a.flow = h->flow;
     a.dH = h->dH; a.dRho = h->dRho; a.dK = h->dK;
     a.status = h->status; a.stats = h->stats; a.wave_diag = h->wave_diag;
-    a.dt = dt; a.n_steps = n_steps;
+    a.dt = dt; a.n_steps = n_steps; a.sync_outer = h->sync_outer;
     return a;
 }
 
@@ -176,7 +177,7 @@ int wt_ensemble_create(int64_t n_reactors, int n_zones, int device, const double
         const int64_t waves = (n_reactors + h->R - 1) / h->R;
         int ns = (int)(waves / 64);
         h->n_sub = ns < 1 ? 1 : (ns > 4 ? 4 : ns);
-        h->chunk_steps = 10;
+        h->chunk_steps = 25;
     }
     hipError_t e = hipMemcpyAsync(h->par, par, sizeof(double) * WT_NP * N, hipMemcpyHostToDevice, h->stream);
     if (e == hipSuccess) e = hipMemsetAsync(h->status, 0, sizeof(uint32_t) * N, h->stream);
@@ -321,6 +322,13 @@ int wt_ensemble_launch_stats(wt_ensemble *h, int64_t *n_launches, double *sum_ms
     }
     *n_launches = (int64_t)(h->lt_used / 2); *sum_ms = sum; *max_ms = mx;
     h->lt_used = 0;
+    return WT_OK;
+}
+
+int wt_ensemble_set_sync(wt_ensemble *h, int sync_outer)
+{
+    if (!h) return fail(WT_E_ARG, "NULL handle");
+    h->sync_outer = sync_outer ? 1 : 0;
     return WT_OK;
 }
 

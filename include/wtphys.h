@@ -101,8 +101,12 @@ int wt_ensemble_step(wt_ensemble *h, double dt, int n_steps, int fused);
 /* Launch schedule: the ensemble is advanced as n_streams contiguous reactor ranges
  * on internal HIP streams (fork/join around the handle's stream), at most
  * chunk_steps outer steps per launch (0 = the whole call in one launch).
- * Default: min(4, wavefronts/64) ranges, 10 steps. */
+ * Default: min(4, wavefronts/64) ranges, 25 steps. */
 int wt_ensemble_set_schedule(wt_ensemble *h, int n_streams, int chunk_steps);
+/* sync_outer != 0: the reactors sharing a wavefront start every outer step together (they wait
+ * for the slowest of them) so that their Jacobian / factorisation / Newton work coincides.
+ * Results are unaffected; it is a throughput knob. */
+int wt_ensemble_set_sync(wt_ensemble *h, int sync_outer);
 int wt_ensemble_synchronize(wt_ensemble *h);
 
 /* ReactorState read-back (reactor.py:113-147).  Any pointer may be NULL.

@@ -11,7 +11,8 @@ ens = wt.ReactorEnsemble(cols, n_zones=n); ens.set_boundary(bc)
 ens.set_schedule(1, 0)  # one range, one launch per call: the diagnostics cover the whole call
 ens.step(1.0, n_steps=100, fused=True, download=False); ens.synchronize()
 ens.wave_diag()
-for label, k, fused in (("stepwise", 1, False), ("stepwise", 1, False), ("fused50", 50, True)):
+for label, k, fused in (("stepwise", 1, False), ("fused50", 50, True), ("fused50-sync", 50, True)):
+    ens.set_sync(label.endswith("sync"))
     ens.timer_start(); ens.step(1.0, n_steps=k, fused=fused, download=False); ms = ens.timer_stop()
     d = ens.wave_diag()
     st = ens.solver_stats()
