@@ -512,6 +512,14 @@ struct FdCols { double D[3][3]; double S[3][3]; }; // [row species][rel+1]: diff
 
 struct ZoneProps { double H, iw, phi, kT, rho; bool bpos; };
 
+// pick x[idx], idx in {0,1,2}, without a runtime-indexed array (those go to scratch memory)
+__device__ __forceinline__ double sel3(double x0, double x1, double x2, int idx)
+{
+    return (idx == 0) ? x0 : ((idx == 1) ? x1 : x2);
+}
+
+// Three colour passes of one species.  Results come back indexed by neighbour offset:
+// out.D[q][r] is the change of this lane's row q when the zone at offset r-1 was perturbed.
 template <bool ROW, int SP>
 __device__ __forceinline__ void fd_species_pass(const Lane &L, const RK &k, const double y[3], const double f[3],
                                                 const ZoneProps &b, double hcol, bool colmask, FdCols &out, bool &bad)
@@ -521,6 +529,7 @@ __device__ __forceinline__ void fd_species_pass(const Lane &L, const RK &k, cons
     if constexpr (SP == SPH) { const PropPH q = prop_pH(k, ypert); p.H = q.H; p.iw = q.iw; p.phi = q.phi; p.bpos = q.bpos; }
     if constexpr (SP == STT) { const PropT q = prop_T(ypert); p.kT = q.kT; p.rho = q.rho; bad = bad || (colmask && q.bad); }
     const int zm = L.z % 3;
+    double Dc[3][3], Sc[3][3];   // [row species][colour], statically indexed
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         const bool mine = (zm == c) && colmask;
@@ -531,15 +540,26 @@ __device__ __forceinline__ void fd_species_pass(const Lane &L, const RK &k, cons
         const double tt = (SP == STT && mine) ? ypert : y[STT];
         double fn[3];
         rhs_rows<ROW>(L, k, H, iw, bpos, kphi, rho, cl, tt, fn);
-        const int rel1 = (c - zm + 4) % 3; // (column zone - this zone) + 1
 #pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            if (rel1 == r) {
+        for (int q = 0; q < 3; ++q) {
+            Dc[q][c] = fn[q] - f[q];
+            Sc[q][c] = fmax(fabs(f[q]), fabs(fn[q]));
+        }
+    }
+    // the zone at offset r-1 has colour (zm + r + 2) mod 3
 #pragma unroll
-                for (int q = 0; q < 3; ++q) {
-                    out.D[q][r] = fn[q] - f[q];
-                    out.S[q][r] = fmax(fabs(f[q]), fabs(fn[q]));
-                }
+    for (int r = 0; r < 3; ++r) {
+        const int c = (zm + r + 2) % 3;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            // rows that cannot depend on a column of species SP are structural zeros
+            const bool dep = (r == 1) ? ((q == SP) || (SP == STT) || (q == SCL && SP == SPH))
+                                      : ((q == SP) || (SP == STT));
+            if (dep) {
+                out.D[q][r] = sel3(Dc[q][0], Dc[q][1], Dc[q][2], c);
+                out.S[q][r] = sel3(Sc[q][0], Sc[q][1], Sc[q][2], c);
+            } else {
+                out.D[q][r] = 0.0; out.S[q][r] = 0.0;
             }
         }
     }
@@ -575,14 +595,6 @@ __device__ __forceinline__ double fd_step(double y, double fac, double ysc)
     return __dadd_rn(__dadd_rn(y, __dmul_rn(fac, ysc)), -y);
 }
 
-__device__ __forceinline__ void zero_cols(FdCols &c)
-{
-#pragma unroll
-    for (int q = 0; q < 3; ++q)
-#pragma unroll
-        for (int r = 0; r < 3; ++r) { c.D[q][r] = 0.0; c.S[q][r] = 0.0; }
-}
-
 // One species' columns: perturb, reduce, optional retry, factor update.  Leaves
 // the finished difference quotients of this species' columns in `cols.D`
 // (already divided by the column's h).
@@ -594,7 +606,6 @@ __device__ __forceinline__ void num_jac_species(const Lane &L, const RK &k, cons
     const double ysc = fs * fmax(ATOL, fabs(y[SP]));
     double h = fd_step(y[SP], fac, ysc);
     while (h == 0) { fac *= 10; h = fd_step(y[SP], fac, ysc); }    // common.py:327-330
-    zero_cols(cols);
     fd_species_pass<ROW, SP>(L, k, y, f, b, h, true, cols, bad);
     double maxd, scl;
     fd_col_reduce<ROW, SP>(L, cols, maxd, scl);
@@ -603,7 +614,6 @@ __device__ __forceinline__ void num_jac_species(const Lane &L, const RK &k, cons
         const double nf = 10 * fac;
         const double hn = fd_step(y[SP], nf, ysc);
         FdCols c2;
-        zero_cols(c2);
         fd_species_pass<ROW, SP>(L, k, y, f, b, hn, small, c2, bad);
         double md2, sc2;
         fd_col_reduce<ROW, SP>(L, c2, md2, sc2);
