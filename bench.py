@@ -104,8 +104,10 @@ def main() -> int:
         print("bench.py: no GPU visible; the physics step has no CPU path", file=sys.stderr)
         return 3
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or "RANK" in os.environ     # launched by torch.distributed.run
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     wt = importlib.import_module("ics-wt-physicsengine_amd")
@@ -117,7 +119,7 @@ def main() -> int:
     def barrier():
         ens.synchronize()
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
 
     if args.streams > 0 or args.chunk != 25:
@@ -141,7 +143,7 @@ def main() -> int:
     ens.launch_timing(False)
 
     el = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device="cuda")
-    if world > 1:
+    if use_dist:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed, kernel_ms = float(el[0]), float(el[1])
 
@@ -150,17 +152,17 @@ def main() -> int:
     local = torch.empty((3, N, n), dtype=torch.float64, device="cuda")
     ens.export_state_device(local.data_ptr())
     ens.synchronize()
-    if world > 1:
+    if use_dist:
         torch.cuda.synchronize(); dist.barrier()
         g0 = time.perf_counter()
-        final = wt.gather_state(local, world)
+        final = wt.gather_state(local, world, force_collective=True)
         torch.cuda.synchronize()
         gather_ms = (time.perf_counter() - g0) * 1e3
     else:
         final = local
     st = ens.status()
     flagged = torch.tensor([int(np.count_nonzero(st))], device="cuda")
-    if world > 1:
+    if use_dist:
         dist.all_reduce(flagged)
     checksum = float(final.sum())
 
@@ -173,6 +175,12 @@ def main() -> int:
         in_flight = (launch_sum_ms / kernel_ms) if kernel_ms > 0 else 1.0   # launches overlapping on the GPU
         bytes_per_launch = algorithmic_bytes_per_zone_step(n) * N * n * args.steps / max(n_launch, 1)
         achieved = bytes_per_launch / avg_launch_s * in_flight / 1e9       # == total bytes / region time
+        # HBM traffic per launch measured offline with rocprofv3 PMC passes for this exact workload
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r1", "traffic.json")
+        if os.path.exists(tpath) and (N, n, args.chunk, n_streams) == (10000, 8, 25, 4):
+            with open(tpath) as fh:
+                traffic = json.load(fh).get("traffic_bytes_per_launch")
         out = {
             "metric": "reactor-zone-steps/sec",
             "value": value,
@@ -198,7 +206,8 @@ def main() -> int:
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_source": "profiles/r1/traffic.json (rocprofv3 FETCH_SIZE + WRITE_SIZE, bytes per launch)" if traffic else None,
                 "kernel": "wt::step_kernel",
                 "avg_launch_us": avg_launch_s * 1e6,
                 "max_launch_us": launch_max_ms * 1e3,
@@ -220,7 +229,7 @@ def main() -> int:
         elif not args.no_cpu_baseline:
             out["cpu_baseline"] = None
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     ens.close()

@@ -22,14 +22,14 @@ def shard_bounds(n_reactors: int, world_size: int, rank: int) -> Tuple[int, int]
     return lo, hi
 
 
-def gather_state(local, world_size: int):
+def gather_state(local, world_size: int, force_collective: bool = False):
     """All-gather equal-sized per-rank state tensors (3, N_local, n) into
     (world_size * N_local reactors) order (3, N_total, n).  ``local`` is a torch
     tensor on the backend's device."""
     import torch
     import torch.distributed as dist
 
-    if world_size == 1:
+    if world_size == 1 and not force_collective:
         return local
     flat = local.contiguous().view(-1)
     out = torch.empty(world_size * flat.numel(), dtype=local.dtype, device=local.device)
