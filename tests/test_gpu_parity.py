@@ -153,6 +153,29 @@ def test_full_size_ensemble_vs_oracle(gpu, wt, oracle, n, N):
     ens_p.close()
 
 
+@pytest.mark.parametrize("n", [4, 8, 20])
+def test_results_do_not_depend_on_the_launch_schedule(gpu, wt, n):
+    """Reactor ranges / streams, steps per launch and the wavefront rendez-vous are throughput
+    knobs: every combination gives bitwise the same state, status and solver counters."""
+    N, steps = 3000, 12
+    cols, bc = wt.make_ensemble(N, seed=4242)
+    ref = None
+    for streams, chunk, sync in ((1, 0, True), (1, 1, False), (4, 5, True), (3, 7, False), (8, 25, True)):
+        ens = wt.ReactorEnsemble(cols, n_zones=n)
+        ens.set_boundary(bc)
+        ens.set_schedule(streams, chunk)
+        ens.set_sync(sync)
+        es = ens.step(1.0, n_steps=steps)
+        got = (es.pH, es.chlorine, es.temperature, es.time, es.status, es.H_concentration, es.density,
+               es.chlorine_decay_rate, ens.solver_stats())
+        if ref is None:
+            ref = got
+        else:
+            for a, b in zip(ref, got):
+                assert np.array_equal(a, b), (streams, chunk, sync)
+        ens.close()
+
+
 @pytest.mark.parametrize("n,N", [(2, 5), (3, 33), (5, 1), (7, 100), (16, 9), (31, 4), (64, 3)])
 def test_ragged_shapes_vs_oracle(gpu, wt, oracle, n, N):
     """Zone counts that do not divide 64, a single reactor, the 64-zone maximum."""
