@@ -500,6 +500,72 @@ __device__ __forceinline__ void solve_cplx(const Lane &L, const Jac &J, const Ld
     br[SPH] = xP.r; bi[SPH] = xP.i; br[SCL] = xC.r; bi[SCL] = xC.i; br[STT] = xT.r; bi[STT] = xT.i;
 }
 
+// Real and complex solve of one Newton iteration, level by level in lock step: the two
+// cyclic-reduction chains are independent, so interleaving them doubles the instruction-level
+// parallelism of what is otherwise one long dependent chain, and each system's factors are
+// fetched from LDS in one batch (one wait per system instead of one per level).
+template <int LV> struct SysFactors { double ra[LV], rg[LV], rinv; cplx ca[LV], cg[LV], cinv; };
+
+template <int LV>
+__device__ __forceinline__ void load_sys(const LdsSlots &F, int k, SysFactors<LV> &s)
+{
+    using S = FSlots<LV>;
+    const int r0 = k * S::RS, c0 = S::CB + k * S::CS;
+#pragma unroll
+    for (int l = 0; l < LV; ++l) {
+        s.ra[l] = F.ld(r0 + 2 * l); s.rg[l] = F.ld(r0 + 2 * l + 1);
+        s.ca[l] = {F.ld(c0 + 4 * l), F.ld(c0 + 4 * l + 1)};
+        s.cg[l] = {F.ld(c0 + 4 * l + 2), F.ld(c0 + 4 * l + 3)};
+    }
+    s.rinv = F.ld(r0 + 2 * LV);
+    s.cinv = {F.ld(c0 + 4 * LV), F.ld(c0 + 4 * LV + 1)};
+}
+
+template <bool ROW, int LV, int l>
+__device__ __forceinline__ void pcr_rc_level(const Lane &L, const SysFactors<LV> &s, double &b, cplx &c)
+{
+    constexpr int st = 1 << l;
+    const bool vlo = L.z - st >= 0, vhi = L.z + st < L.n;
+    const double b_lo = keep_if(vlo, from_lo<ROW, st>(b)), b_hi = keep_if(vhi, from_hi<ROW, st>(b));
+    const cplx c_lo = {keep_if(vlo, from_lo<ROW, st>(c.r)), keep_if(vlo, from_lo<ROW, st>(c.i))};
+    const cplx c_hi = {keep_if(vhi, from_hi<ROW, st>(c.r)), keep_if(vhi, from_hi<ROW, st>(c.i))};
+    b = b - s.ra[l] * b_lo - s.rg[l] * b_hi;
+    const cplx t1 = cmul(s.ca[l], c_lo), t2 = cmul(s.cg[l], c_hi);
+    c = {c.r - t1.r - t2.r, c.i - t1.i - t2.i};
+    if constexpr (l + 1 < LV) pcr_rc_level<ROW, LV, l + 1>(L, s, b, c);
+}
+
+template <bool ROW, int LV>
+__device__ __forceinline__ void solve_rc(const Lane &L, const Jac &J, const LdsSlots &F,
+                                         double br[3], double cr[3], double ci[3])
+{
+    SysFactors<LV> sT, sP, sC;
+    load_sys<LV>(F, 0, sT);
+    load_sys<LV>(F, 1, sP);
+    // temperature block
+    double xT = br[STT]; cplx zT = {cr[STT], ci[STT]};
+    pcr_rc_level<ROW, LV, 0>(L, sT, xT, zT);
+    xT *= sT.rinv; zT = cmul(zT, sT.cinv);
+    load_sys<LV>(F, 2, sC);
+    const double xT_lo = keep_if(L.has_lo, from_lo<ROW, 1>(xT)), xT_hi = keep_if(L.has_hi, from_hi<ROW, 1>(xT));
+    const cplx zT_lo = {keep_if(L.has_lo, from_lo<ROW, 1>(zT.r)), keep_if(L.has_lo, from_lo<ROW, 1>(zT.i))};
+    const cplx zT_hi = {keep_if(L.has_hi, from_hi<ROW, 1>(zT.r)), keep_if(L.has_hi, from_hi<ROW, 1>(zT.i))};
+    // pH block: rhs += J_pT x_T
+    double xP = br[SPH] + (J.pt[0] * xT_lo + J.pt[1] * xT + J.pt[2] * xT_hi);
+    cplx zP = {cr[SPH] + (J.pt[0] * zT_lo.r + J.pt[1] * zT.r + J.pt[2] * zT_hi.r),
+               ci[SPH] + (J.pt[0] * zT_lo.i + J.pt[1] * zT.i + J.pt[2] * zT_hi.i)};
+    pcr_rc_level<ROW, LV, 0>(L, sP, xP, zP);
+    xP *= sP.rinv; zP = cmul(zP, sP.cinv);
+    // chlorine block: rhs += J_cT x_T + J_cp x_p
+    double xC = br[SCL] + (J.ct[0] * xT_lo + J.ct[1] * xT + J.ct[2] * xT_hi) + J.cp * xP;
+    cplx zC = {cr[SCL] + (J.ct[0] * zT_lo.r + J.ct[1] * zT.r + J.ct[2] * zT_hi.r) + J.cp * zP.r,
+               ci[SCL] + (J.ct[0] * zT_lo.i + J.ct[1] * zT.i + J.ct[2] * zT_hi.i) + J.cp * zP.i};
+    pcr_rc_level<ROW, LV, 0>(L, sC, xC, zC);
+    xC *= sC.rinv; zC = cmul(zC, sC.cinv);
+    br[SPH] = xP; br[SCL] = xC; br[STT] = xT;
+    cr[SPH] = zP.r; ci[SPH] = zP.i; cr[SCL] = zC.r; ci[SCL] = zC.i; cr[STT] = zT.r; ci[STT] = zT.i;
+}
+
 // ---------------------------------------------------------------- num_jac (common.py:257-382)
 // Forward differences restated for the banded structure: perturbing zone j only
 // changes rows of zones j-1..j+1, so zones of equal (j mod 3) are perturbed
@@ -998,8 +1064,7 @@ __global__ __launch_bounds__(64) void step_kernel(const StepArgs a)
                     fcr[q] = re - (Mcr * W[1][q] - Mci * W[2][q]);
                     fci[q] = im - (Mcr * W[2][q] + Mci * W[1][q]);
                 }
-                solve_real<ROW, LV>(L, J, F, fr);
-                solve_cplx<ROW, LV>(L, J, F, fcr, fci);
+                solve_rc<ROW, LV>(L, J, F, fr, fcr, fci);
                 double ssum = 0.0;
 #pragma unroll
                 for (int q = 0; q < 3; ++q) {
