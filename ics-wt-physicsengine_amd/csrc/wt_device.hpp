@@ -452,20 +452,75 @@ __device__ __forceinline__ cplx pcr_solve_cplx(const Lane &L, const LdsSlots &F,
     return cmul(b, {F.ld(s0 + 4 * LV), F.ld(s0 + 4 * LV + 1)});
 }
 
+// One cyclic-reduction level of all six systems (three real, three complex shift) at once: the
+// six eliminations are independent, so issuing them together hides the reciprocal / DPP latency
+// of each behind the others.
+template <bool ROW, int LV, int l>
+__device__ __forceinline__ void pcr_factor_level_all(const Lane &L, double ar[3], double dr[3], double cr[3],
+                                                     cplx ac[3], cplx dc[3], cplx cc[3], const LdsSlots &F)
+{
+    using S = FSlots<LV>;
+    constexpr int s = 1 << l;
+    const bool vlo = L.z - s >= 0, vhi = L.z + s < L.n;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        // real shift
+        const double d_lo = from_lo<ROW, s>(dr[k]), d_hi = from_hi<ROW, s>(dr[k]);
+        const double a_lo = from_lo<ROW, s>(ar[k]), c_lo = from_lo<ROW, s>(cr[k]);
+        const double a_hi = from_hi<ROW, s>(ar[k]), c_hi = from_hi<ROW, s>(cr[k]);
+        // a == 0 where there is no lower neighbour (c likewise), so alpha/gamma vanish there by
+        // themselves once the foreign operands are finite
+        const double al = ar[k] * rcp(vlo ? d_lo : 1.0);
+        const double ga = cr[k] * rcp(vhi ? d_hi : 1.0);
+        dr[k] = dr[k] - al * keep_if(vlo, c_lo) - ga * keep_if(vhi, a_hi);
+        ar[k] = -al * keep_if(vlo, a_lo);
+        cr[k] = -ga * keep_if(vhi, c_hi);
+        F.st(k * S::RS + 2 * l, al); F.st(k * S::RS + 2 * l + 1, ga);
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        // complex shift
+        const cplx d_lo = cfrom_lo<ROW, s>(dc[k]), d_hi = cfrom_hi<ROW, s>(dc[k]);
+        const cplx a_lo = cfrom_lo<ROW, s>(ac[k]), c_lo = cfrom_lo<ROW, s>(cc[k]);
+        const cplx a_hi = cfrom_hi<ROW, s>(ac[k]), c_hi = cfrom_hi<ROW, s>(cc[k]);
+        const cplx dl = {vlo ? d_lo.r : 1.0, keep_if(vlo, d_lo.i)};
+        const cplx dh = {vhi ? d_hi.r : 1.0, keep_if(vhi, d_hi.i)};
+        const cplx al = cmul(ac[k], cinv(dl));
+        const cplx ga = cmul(cc[k], cinv(dh));
+        const cplx t1 = cmul(al, {keep_if(vlo, c_lo.r), keep_if(vlo, c_lo.i)});
+        const cplx t2 = cmul(ga, {keep_if(vhi, a_hi.r), keep_if(vhi, a_hi.i)});
+        dc[k] = {dc[k].r - t1.r - t2.r, dc[k].i - t1.i - t2.i};
+        const cplx na = cmul(al, {keep_if(vlo, a_lo.r), keep_if(vlo, a_lo.i)});
+        const cplx nc = cmul(ga, {keep_if(vhi, c_hi.r), keep_if(vhi, c_hi.i)});
+        ac[k] = {-na.r, -na.i};
+        cc[k] = {-nc.r, -nc.i};
+        const int c0 = S::CB + k * S::CS + 4 * l;
+        F.st(c0, al.r); F.st(c0 + 1, al.i); F.st(c0 + 2, ga.r); F.st(c0 + 3, ga.i);
+    }
+    if constexpr (l + 1 < LV) pcr_factor_level_all<ROW, LV, l + 1>(L, ar, dr, cr, ac, dc, cc, F);
+}
+
 // The six factored systems of one (h, J) pair: scipy's LU_real / LU_complex.
 template <bool ROW, int LV>
 __device__ __forceinline__ void factorize(const Lane &L, const Jac &J, double h, const LdsSlots &F)
 {
     using S = FSlots<LV>;
-    // radau.py:454-456: MU_REAL / h * I - J ; MU_COMPLEX / h * I - J
+    // radau.py:454-456: MU_REAL / h * I - J ; MU_COMPLEX / h * I - J   (systems: 0 = T, 1 = pH, 2 = Cl)
     const double ih = rcp(h);
     const double mr = rc::MU_REAL * ih, mcr = rc::MU_CR * ih, mci = rc::MU_CI * ih;
-    pcr_factor_real<ROW, LV>(L, -J.tt[0], mr - J.tt[1], -J.tt[2], F, 0 * S::RS);
-    pcr_factor_real<ROW, LV>(L, -J.pp[0], mr - J.pp[1], -J.pp[2], F, 1 * S::RS);
-    pcr_factor_real<ROW, LV>(L, -J.cc[0], mr - J.cc[1], -J.cc[2], F, 2 * S::RS);
-    pcr_factor_cplx<ROW, LV>(L, -J.tt[0], {mcr - J.tt[1], mci}, -J.tt[2], F, S::CB + 0 * S::CS);
-    pcr_factor_cplx<ROW, LV>(L, -J.pp[0], {mcr - J.pp[1], mci}, -J.pp[2], F, S::CB + 1 * S::CS);
-    pcr_factor_cplx<ROW, LV>(L, -J.cc[0], {mcr - J.cc[1], mci}, -J.cc[2], F, S::CB + 2 * S::CS);
+    double ar[3] = {-J.tt[0], -J.pp[0], -J.cc[0]};
+    double dr[3] = {mr - J.tt[1], mr - J.pp[1], mr - J.cc[1]};
+    double cr[3] = {-J.tt[2], -J.pp[2], -J.cc[2]};
+    cplx ac[3] = {{ar[0], 0.0}, {ar[1], 0.0}, {ar[2], 0.0}};
+    cplx dc[3] = {{mcr - J.tt[1], mci}, {mcr - J.pp[1], mci}, {mcr - J.cc[1], mci}};
+    cplx cc[3] = {{cr[0], 0.0}, {cr[1], 0.0}, {cr[2], 0.0}};
+    pcr_factor_level_all<ROW, LV, 0>(L, ar, dr, cr, ac, dc, cc, F);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        F.st(k * S::RS + 2 * LV, rcp(dr[k]));
+        const cplx inv = cinv(dc[k]);
+        F.st(S::CB + k * S::CS + 4 * LV, inv.r); F.st(S::CB + k * S::CS + 4 * LV + 1, inv.i);
+    }
 }
 
 // x = (mu_real/h I - J)^-1 b, in place, b indexed by species
