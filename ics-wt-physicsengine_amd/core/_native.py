@@ -15,7 +15,7 @@ import numpy as np
 
 _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(_PKG, "csrc")
-LIB_PATH = os.path.join(CSRC, "libwtphys.so")
+LIB_PATH = os.environ.get("WTPHYS_LIB", os.path.join(CSRC, "libwtphys.so"))  # override: diagnostic builds
 
 WT_OK, WT_E_ARG, WT_E_HIP, WT_E_NOGPU, WT_E_STATE = 0, 1, 2, 3, 4
 
@@ -64,6 +64,7 @@ def lib():
     L = C.CDLL(LIB_PATH)
     dp, u32p, i32p, vp = C.POINTER(C.c_double), C.POINTER(C.c_uint32), C.POINTER(C.c_int32), C.c_void_p
     L.wt_abi_version.restype = C.c_int
+    L.wt_wave_diag_slots.restype = C.c_int
     L.wt_last_error.restype = C.c_char_p
     L.wt_device_count.argtypes = [C.POINTER(C.c_int)]
     L.wt_ensemble_create.argtypes = [C.c_int64, C.c_int, C.c_int, dp, C.POINTER(vp)]

@@ -345,7 +345,7 @@ class ReactorEnsemble:
             self._diag_on = True
             return None
         _native.check(L.wt_ensemble_wave_diag(self._h, None, 0, C.byref(nw)))
-        out = np.zeros((nw.value, 8), dtype=np.int64)
+        out = np.zeros((nw.value, L.wt_wave_diag_slots()), dtype=np.int64)
         _native.check(L.wt_ensemble_wave_diag(self._h, out.ctypes.data_as(C.POINTER(C.c_int64)), nw.value, C.byref(nw)))
         return out
 

@@ -33,6 +33,12 @@
 
 namespace wt {
 
+#ifdef WT_STAMPS
+constexpr int WT_DIAG_SLOTS = 16;
+#else
+constexpr int WT_DIAG_SLOTS = 8;
+#endif
+
 constexpr int SPH = 0, SCL = 1, STT = 2;  // species index inside a lane
 constexpr double RTOL = 1e-6, ATOL = 1e-8; // reactor.py:481-483
 constexpr int NEWTON_MAXITER = 6;          // radau.py:43
@@ -877,6 +883,12 @@ __global__ __launch_bounds__(64) void step_kernel(const StepArgs a)
     bool jac_after_fnew = false;  // that step also asked for a fresh Jacobian (radau.py:500,512)
     int phase = PH_OUTER_BEGIN;
     long long diag_trips = 0, diag_newton = 0, diag_fact = 0, diag_jac = 0, diag_f3 = 0;
+#ifdef WT_STAMPS  // diagnostic build only: shader-clock shares of the loop's sections (never in the product .so)
+    long long sec[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long tprev = __builtin_amdgcn_s_memtime();
+#define WT_STAMP(i) do { const long long tn_ = __builtin_amdgcn_s_memtime(); sec[i] += tn_ - tprev; tprev = tn_; } while (0)
+#else
+#define WT_STAMP(i) do { } while (0)
+#endif
 
     // select_initial_step (common.py:68-134), order 3, up to the probe point y0 + h0 f0
     auto initial_step_first_half = [&]() {
@@ -966,6 +978,7 @@ __global__ __launch_bounds__(64) void step_kernel(const StepArgs a)
             }
         }
         if (__ballot(phase != PH_EXIT) == 0ull) break;
+        WT_STAMP(0);   // outer-step bookkeeping
 
         if (phase == PH_OUTER_BEGIN) {
             // a fresh scipy solver object per outer step (reactor.py:476)
@@ -1033,12 +1046,14 @@ __global__ __launch_bounds__(64) void step_kernel(const StepArgs a)
                 phase = PH_NEWTON;
             }
         }
+        WT_STAMP(1);   // step / attempt prologues
         if (__ballot(phase == PH_NEWTON && !have_lu) != 0ull) diag_fact++;
         if (phase == PH_NEWTON && !have_lu) {
             factorize<ROW, LV>(L, J, h, F); have_lu = true; cnt.nlu += 2;      // radau.py:454-456
         }
 
 
+        WT_STAMP(2);   // factorisation
         // ================= this trip's evaluation points
         const bool newton = (phase == PH_NEWTON);
         diag_trips++; if (__ballot(newton) != 0ull) diag_newton++;
@@ -1058,14 +1073,18 @@ __global__ __launch_bounds__(64) void step_kernel(const StepArgs a)
             if (newton) p0 = yc[q] + z0;
             ye[0][q] = p0; ye[1][q] = yc[q] + z1; ye[2][q] = yc[q] + z2;
         }
-        if (eval0) {
-            bad |= rhs_full<ROW>(L, k, ye[0], Fe[0]);
-            if (phase != PH_FNEW) cnt.nfev++;
-        }
-        if (newton) {
-            bad |= rhs_full<ROW>(L, k, ye[1], Fe[1]);
-            bad |= rhs_full<ROW>(L, k, ye[2], Fe[2]);
-            cnt.nfev += 2;
+        if (__ballot(newton) != 0ull) {
+            // some reactor of the wavefront is in its Newton phase: all three stage points in one
+            // straight-line block (three independent chains for the scheduler to interleave); the
+            // other lanes' slot-1/2 results are simply not used
+            const bool b0 = rhs_full<ROW>(L, k, ye[0], Fe[0]);
+            const bool b1 = rhs_full<ROW>(L, k, ye[1], Fe[1]);
+            const bool b2 = rhs_full<ROW>(L, k, ye[2], Fe[2]);
+            if (eval0) { bad |= b0; if (phase != PH_FNEW) cnt.nfev++; }
+            if (newton) { bad |= b1 | b2; cnt.nfev += 2; }
+        } else if (__ballot(eval0) != 0ull) {
+            const bool b0 = rhs_full<ROW>(L, k, ye[0], Fe[0]);
+            if (eval0) { bad |= b0; if (phase != PH_FNEW) cnt.nfev++; }
         }
         if (__ballot(eval3) != 0ull) {
             diag_f3++;
@@ -1078,6 +1097,7 @@ __global__ __launch_bounds__(64) void step_kernel(const StepArgs a)
             }
         }
         if (seg_any(L, bad)) { bad = true; if (phase != PH_EXIT) phase = PH_OUTER_END; }
+        WT_STAMP(3);   // RHS evaluations
 
         // ================= per-phase epilogues
         if (phase == PH_OUTER_BEGIN) {
@@ -1197,6 +1217,7 @@ __global__ __launch_bounds__(64) void step_kernel(const StepArgs a)
             phase = ((t - t_bound) < 0) ? PH_STEP_BEGIN : PH_OUTER_END;
         }
 
+        WT_STAMP(4);   // epilogues (Newton solve, error estimate, accept / reject)
         // ================= finite-difference Jacobian at (yc, f) when a phase asked for it
         if (__ballot(need_jac) != 0ull) diag_jac++;
         if (need_jac) {
@@ -1205,11 +1226,15 @@ __global__ __launch_bounds__(64) void step_kernel(const StepArgs a)
             need_jac = false;
             if (seg_any(L, jbad)) { bad = true; phase = PH_OUTER_END; }
         }
+        WT_STAMP(5);   // num_jac
     }
 
     if (a.wave_diag && (threadIdx.x & 63) == 0) {
-        int64_t *o = a.wave_diag + (a.r0 / a.R + (int64_t)blockIdx.x) * 8;
+        int64_t *o = a.wave_diag + (a.r0 / a.R + (int64_t)blockIdx.x) * WT_DIAG_SLOTS;
         o[0] = diag_trips; o[1] = diag_newton; o[4] = diag_fact; o[5] = diag_jac; o[6] = diag_f3; o[7] = 0;
+#ifdef WT_STAMPS
+        for (int i = 0; i < 8; ++i) o[8 + i] = sec[i];
+#endif
         o[2] = __builtin_amdgcn_s_memtime() - clk0; o[3] = __builtin_amdgcn_s_memrealtime() - wall0;
     }
     if (advanced) {

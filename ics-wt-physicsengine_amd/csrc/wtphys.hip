@@ -495,6 +495,8 @@ int wt_selftest_shuffles(int device, int n_zones, int *mismatches)
     return WT_OK;
 }
 
+int wt_wave_diag_slots(void) { return wt::WT_DIAG_SLOTS; }
+
 int wt_ensemble_wave_diag(wt_ensemble *h, int64_t *out, int64_t capacity, int64_t *n_waves)
 {
     if (!h || !n_waves) return fail(WT_E_ARG, "NULL argument");
@@ -502,14 +504,14 @@ int wt_ensemble_wave_diag(wt_ensemble *h, int64_t *out, int64_t capacity, int64_
     const int64_t nw = (h->N + h->R - 1) / h->R;
     *n_waves = nw;
     if (!h->wave_diag) {   // first call switches the diagnostics on
-        HIP_TRY(hipMalloc((void **)&h->wave_diag, sizeof(int64_t) * 8 * (size_t)nw));
-        HIP_TRY(hipMemsetAsync(h->wave_diag, 0, sizeof(int64_t) * 8 * (size_t)nw, h->stream));
+        HIP_TRY(hipMalloc((void **)&h->wave_diag, sizeof(int64_t) * wt::WT_DIAG_SLOTS * (size_t)nw));
+        HIP_TRY(hipMemsetAsync(h->wave_diag, 0, sizeof(int64_t) * wt::WT_DIAG_SLOTS * (size_t)nw, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
         return WT_OK;
     }
     if (out) {
         if (capacity < nw) return fail(WT_E_ARG, "wave_diag buffer too small");
-        HIP_TRY(hipMemcpyAsync(out, h->wave_diag, sizeof(int64_t) * 8 * (size_t)nw, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipMemcpyAsync(out, h->wave_diag, sizeof(int64_t) * wt::WT_DIAG_SLOTS * (size_t)nw, hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
     }
     return WT_OK;

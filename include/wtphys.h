@@ -151,7 +151,9 @@ int wt_selftest_shuffles(int device, int n_zones, int *mismatches);
  * evaluation, shader clocks, 100 MHz wall ticks, factorisation / Jacobian /
  * deferred-f block executions, spare} per wavefront.  The first call allocates the
  * buffer and switches recording on (out may be NULL); later calls copy
- * [n_waves][8] int64 into `out`. */
+ * [n_waves][wt_wave_diag_slots()] int64 into `out` (8 slots; 16 in -DWT_STAMPS diagnostic builds,
+ * which add the shader-clock shares of the kernel loop's sections). */
+int wt_wave_diag_slots(void);
 int wt_ensemble_wave_diag(wt_ensemble *h, int64_t *out, int64_t capacity, int64_t *n_waves);
 
 int64_t wt_ensemble_size(const wt_ensemble *h);

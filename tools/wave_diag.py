@@ -21,5 +21,10 @@ for label, k, fused in (("stepwise", 1, False), ("fused50", 50, True), ("fused50
           f" | wave us/step mean {wall.mean():.1f} p50 {np.median(wall):.1f} p90 {np.percentile(wall,90):.1f} p99 {np.percentile(wall,99):.1f} max {wall.max():.1f}"
           f" | fact {d[:,4].mean()/k:.2f} jac {d[:,5].mean()/k:.2f} f3 {d[:,6].mean()/k:.2f}"
           f" | clk/wall GHz {np.mean(clk/wall)/1e3:.2f} | reactor nfev mean {st[:,0].mean():.1f} max {st[:,0].max()}")
+    if d.shape[1] > 8:
+        names = ["outer", "prologue", "factorize", "rhs", "epilogue", "num_jac", "-", "-"]
+        tot = d[:, 8:16].sum()
+        print("   section shares: " + "  ".join(f"{nm} {d[:, 8 + i].sum() / tot * 100:.1f}%" for i, nm in enumerate(names) if nm != "-")
+              + f" | stamped clocks/step {d[:, 8:16].sum(1).mean() / k:.0f}")
     if k == 1:
         srt = np.sort(wall)[::-1][:8]; print("   slowest waves us:", np.round(srt, 1), "trips:", np.sort(d[:, 0])[::-1][:8])
