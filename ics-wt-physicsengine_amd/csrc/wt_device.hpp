@@ -349,15 +349,21 @@ struct Jac {
 // A factor is written once per (h, J) and read once per solve, so LDS traffic is
 // off the fp64 VALU pipe that bounds this kernel, and the register file keeps
 // room for two wavefronts per SIMD.
-struct LdsSlots {
-    double *base;   // this lane's column: base[slot * 64]
-    __device__ __forceinline__ double ld(int slot) const { return base[slot * 64]; }
-    __device__ __forceinline__ void st(int slot, double v) const { base[slot * 64] = v; }
+// For n > 8 (LV >= 4) the real-shift factors stay in registers instead (a lone wavefront has
+// them to spare) so that the LDS footprint still admits 4-5 wavefronts per CU.
+template <int LV> struct FStore {
+    static constexpr int NREG = (LV >= 4) ? 3 * (2 * LV + 1) : 0;   // slots [0, NREG) in registers
+    double reg[NREG > 0 ? NREG : 1];
+    double *base;   // this lane's LDS column: base[(slot - NREG) * 64]
+    // `slot` is a compile-time constant at every call site after inlining / unrolling
+    __device__ __forceinline__ double ld(int slot) const { return (slot < NREG) ? reg[slot < NREG ? slot : 0] : base[(slot - NREG) * 64]; }
+    __device__ __forceinline__ void st(int slot, double v) { if (slot < NREG) reg[slot < NREG ? slot : 0] = v; else base[(slot - NREG) * 64] = v; }
 };
 // slot map: real system k (0..2): [k*(2LV+1) + 2l] = alpha_l, [+2l+1] = gamma_l, [+2LV] = 1/d
 //           complex system k:      CB + k*(4LV+2) + 4l + {0,1,2,3} = al.r, al.i, ga.r, ga.i; [+4LV, +4LV+1] = 1/d
 template <int LV> struct FSlots {
     static constexpr int RS = 2 * LV + 1, CS = 4 * LV + 2, CB = 3 * RS, TOTAL = 3 * RS + 3 * CS;
+    static constexpr int LDS_SLOTS = TOTAL - FStore<LV>::NREG;
 };
 
 struct cplx { double r, i; };
@@ -365,32 +371,7 @@ __device__ __forceinline__ cplx cmul(cplx a, cplx b) { return {a.r * b.r - a.i *
 __device__ __forceinline__ cplx cinv(cplx a) { const double q = rcp(a.r * a.r + a.i * a.i); return {a.r * q, -a.i * q}; }
 
 template <bool ROW, int LV, int l>
-__device__ __forceinline__ void pcr_factor_real_level(const Lane &L, double &a, double &d, double &c, const LdsSlots &F, int s0)
-{
-    constexpr int s = 1 << l;
-    const bool vlo = L.z - s >= 0, vhi = L.z + s < L.n;
-    const double d_lo = from_lo<ROW, s>(d), d_hi = from_hi<ROW, s>(d);
-    const double a_lo = from_lo<ROW, s>(a), c_lo = from_lo<ROW, s>(c);
-    const double a_hi = from_hi<ROW, s>(a), c_hi = from_hi<ROW, s>(c);
-    // a == 0 where there is no lower neighbour (c likewise), so alpha/gamma vanish there by
-    // themselves once the foreign operands are finite
-    const double al = a * rcp(vlo ? d_lo : 1.0);
-    const double ga = c * rcp(vhi ? d_hi : 1.0);
-    d = d - al * keep_if(vlo, c_lo) - ga * keep_if(vhi, a_hi);
-    a = -al * keep_if(vlo, a_lo);
-    c = -ga * keep_if(vhi, c_hi);
-    F.st(s0 + 2 * l, al); F.st(s0 + 2 * l + 1, ga);
-    if constexpr (l + 1 < LV) pcr_factor_real_level<ROW, LV, l + 1>(L, a, d, c, F, s0);
-}
-template <bool ROW, int LV>
-__device__ __forceinline__ void pcr_factor_real(const Lane &L, double a, double d, double c, const LdsSlots &F, int s0)
-{
-    pcr_factor_real_level<ROW, LV, 0>(L, a, d, c, F, s0);
-    F.st(s0 + 2 * LV, rcp(d));
-}
-
-template <bool ROW, int LV, int l>
-__device__ __forceinline__ void pcr_solve_real_level(const Lane &L, const LdsSlots &F, int s0, double &b)
+__device__ __forceinline__ void pcr_solve_real_level(const Lane &L, const FStore<LV> &F, int s0, double &b)
 {
     constexpr int s = 1 << l;
     const bool vlo = L.z - s >= 0, vhi = L.z + s < L.n;
@@ -399,7 +380,7 @@ __device__ __forceinline__ void pcr_solve_real_level(const Lane &L, const LdsSlo
     if constexpr (l + 1 < LV) pcr_solve_real_level<ROW, LV, l + 1>(L, F, s0, b);
 }
 template <bool ROW, int LV>
-__device__ __forceinline__ double pcr_solve_real(const Lane &L, const LdsSlots &F, int s0, double b)
+__device__ __forceinline__ double pcr_solve_real(const Lane &L, const FStore<LV> &F, int s0, double b)
 {
     pcr_solve_real_level<ROW, LV, 0>(L, F, s0, b);
     return b * F.ld(s0 + 2 * LV);
@@ -408,62 +389,12 @@ __device__ __forceinline__ double pcr_solve_real(const Lane &L, const LdsSlots &
 template <bool ROW, int S> __device__ __forceinline__ cplx cfrom_lo(cplx a) { return {from_lo<ROW, S>(a.r), from_lo<ROW, S>(a.i)}; }
 template <bool ROW, int S> __device__ __forceinline__ cplx cfrom_hi(cplx a) { return {from_hi<ROW, S>(a.r), from_hi<ROW, S>(a.i)}; }
 
-template <bool ROW, int LV, int l>
-__device__ __forceinline__ void pcr_factor_cplx_level(const Lane &L, cplx &a, cplx &d, cplx &c, const LdsSlots &F, int s0)
-{
-    constexpr int s = 1 << l;
-    const bool vlo = L.z - s >= 0, vhi = L.z + s < L.n;
-    const cplx d_lo = cfrom_lo<ROW, s>(d), d_hi = cfrom_hi<ROW, s>(d);
-    const cplx a_lo = cfrom_lo<ROW, s>(a), c_lo = cfrom_lo<ROW, s>(c);
-    const cplx a_hi = cfrom_hi<ROW, s>(a), c_hi = cfrom_hi<ROW, s>(c);
-    const cplx dl = {vlo ? d_lo.r : 1.0, keep_if(vlo, d_lo.i)};
-    const cplx dh = {vhi ? d_hi.r : 1.0, keep_if(vhi, d_hi.i)};
-    const cplx al = cmul(a, cinv(dl));   // a == 0 without a lower neighbour => alpha == 0
-    const cplx ga = cmul(c, cinv(dh));
-    const cplx t1 = cmul(al, {keep_if(vlo, c_lo.r), keep_if(vlo, c_lo.i)});
-    const cplx t2 = cmul(ga, {keep_if(vhi, a_hi.r), keep_if(vhi, a_hi.i)});
-    d = {d.r - t1.r - t2.r, d.i - t1.i - t2.i};
-    const cplx na = cmul(al, {keep_if(vlo, a_lo.r), keep_if(vlo, a_lo.i)});
-    const cplx nc = cmul(ga, {keep_if(vhi, c_hi.r), keep_if(vhi, c_hi.i)});
-    a = {-na.r, -na.i};
-    c = {-nc.r, -nc.i};
-    F.st(s0 + 4 * l, al.r); F.st(s0 + 4 * l + 1, al.i); F.st(s0 + 4 * l + 2, ga.r); F.st(s0 + 4 * l + 3, ga.i);
-    if constexpr (l + 1 < LV) pcr_factor_cplx_level<ROW, LV, l + 1>(L, a, d, c, F, s0);
-}
-template <bool ROW, int LV>
-__device__ __forceinline__ void pcr_factor_cplx(const Lane &L, double a0, cplx d, double c0, const LdsSlots &F, int s0)
-{
-    cplx a = {a0, 0.0}, c = {c0, 0.0};
-    pcr_factor_cplx_level<ROW, LV, 0>(L, a, d, c, F, s0);
-    const cplx inv = cinv(d);
-    F.st(s0 + 4 * LV, inv.r); F.st(s0 + 4 * LV + 1, inv.i);
-}
-
-template <bool ROW, int LV, int l>
-__device__ __forceinline__ void pcr_solve_cplx_level(const Lane &L, const LdsSlots &F, int s0, cplx &b)
-{
-    constexpr int s = 1 << l;
-    const bool vlo = L.z - s >= 0, vhi = L.z + s < L.n;
-    const cplx b_lo_r = cfrom_lo<ROW, s>(b), b_hi_r = cfrom_hi<ROW, s>(b);
-    const cplx b_lo = {keep_if(vlo, b_lo_r.r), keep_if(vlo, b_lo_r.i)}, b_hi = {keep_if(vhi, b_hi_r.r), keep_if(vhi, b_hi_r.i)};
-    const cplx t1 = cmul({F.ld(s0 + 4 * l), F.ld(s0 + 4 * l + 1)}, b_lo);
-    const cplx t2 = cmul({F.ld(s0 + 4 * l + 2), F.ld(s0 + 4 * l + 3)}, b_hi);
-    b = {b.r - t1.r - t2.r, b.i - t1.i - t2.i};
-    if constexpr (l + 1 < LV) pcr_solve_cplx_level<ROW, LV, l + 1>(L, F, s0, b);
-}
-template <bool ROW, int LV>
-__device__ __forceinline__ cplx pcr_solve_cplx(const Lane &L, const LdsSlots &F, int s0, cplx b)
-{
-    pcr_solve_cplx_level<ROW, LV, 0>(L, F, s0, b);
-    return cmul(b, {F.ld(s0 + 4 * LV), F.ld(s0 + 4 * LV + 1)});
-}
-
 // One cyclic-reduction level of all six systems (three real, three complex shift) at once: the
 // six eliminations are independent, so issuing them together hides the reciprocal / DPP latency
 // of each behind the others.
 template <bool ROW, int LV, int l>
 __device__ __forceinline__ void pcr_factor_level_all(const Lane &L, double ar[3], double dr[3], double cr[3],
-                                                     cplx ac[3], cplx dc[3], cplx cc[3], const LdsSlots &F)
+                                                     cplx ac[3], cplx dc[3], cplx cc[3], FStore<LV> &F)
 {
     using S = FSlots<LV>;
     constexpr int s = 1 << l;
@@ -508,7 +439,7 @@ __device__ __forceinline__ void pcr_factor_level_all(const Lane &L, double ar[3]
 
 // The six factored systems of one (h, J) pair: scipy's LU_real / LU_complex.
 template <bool ROW, int LV>
-__device__ __forceinline__ void factorize(const Lane &L, const Jac &J, double h, const LdsSlots &F)
+__device__ __forceinline__ void factorize(const Lane &L, const Jac &J, double h, FStore<LV> &F)
 {
     using S = FSlots<LV>;
     // radau.py:454-456: MU_REAL / h * I - J ; MU_COMPLEX / h * I - J   (systems: 0 = T, 1 = pH, 2 = Cl)
@@ -531,7 +462,7 @@ __device__ __forceinline__ void factorize(const Lane &L, const Jac &J, double h,
 
 // x = (mu_real/h I - J)^-1 b, in place, b indexed by species
 template <bool ROW, int LV>
-__device__ __forceinline__ void solve_real(const Lane &L, const Jac &J, const LdsSlots &F, double b[3])
+__device__ __forceinline__ void solve_real(const Lane &L, const Jac &J, const FStore<LV> &F, double b[3])
 {
     using S = FSlots<LV>;
     const double xT = pcr_solve_real<ROW, LV>(L, F, 0 * S::RS, b[STT]);
@@ -544,23 +475,6 @@ __device__ __forceinline__ void solve_real(const Lane &L, const Jac &J, const Ld
     b[SPH] = xP; b[SCL] = xC; b[STT] = xT;
 }
 
-template <bool ROW, int LV>
-__device__ __forceinline__ void solve_cplx(const Lane &L, const Jac &J, const LdsSlots &F, double br[3], double bi[3])
-{
-    using S = FSlots<LV>;
-    const cplx xT = pcr_solve_cplx<ROW, LV>(L, F, S::CB + 0 * S::CS, {br[STT], bi[STT]});
-    const cplx xT_lo_r = cfrom_lo<ROW, 1>(xT), xT_hi_r = cfrom_hi<ROW, 1>(xT);
-    const cplx xT_lo = {keep_if(L.has_lo, xT_lo_r.r), keep_if(L.has_lo, xT_lo_r.i)};
-    const cplx xT_hi = {keep_if(L.has_hi, xT_hi_r.r), keep_if(L.has_hi, xT_hi_r.i)};
-    const cplx bp = {br[SPH] + (J.pt[0] * xT_lo.r + J.pt[1] * xT.r + J.pt[2] * xT_hi.r),
-                     bi[SPH] + (J.pt[0] * xT_lo.i + J.pt[1] * xT.i + J.pt[2] * xT_hi.i)};
-    const cplx xP = pcr_solve_cplx<ROW, LV>(L, F, S::CB + 1 * S::CS, bp);
-    const cplx bc = {br[SCL] + (J.ct[0] * xT_lo.r + J.ct[1] * xT.r + J.ct[2] * xT_hi.r) + J.cp * xP.r,
-                     bi[SCL] + (J.ct[0] * xT_lo.i + J.ct[1] * xT.i + J.ct[2] * xT_hi.i) + J.cp * xP.i};
-    const cplx xC = pcr_solve_cplx<ROW, LV>(L, F, S::CB + 2 * S::CS, bc);
-    br[SPH] = xP.r; bi[SPH] = xP.i; br[SCL] = xC.r; bi[SCL] = xC.i; br[STT] = xT.r; bi[STT] = xT.i;
-}
-
 // Real and complex solve of one Newton iteration, level by level in lock step: the two
 // cyclic-reduction chains are independent, so interleaving them doubles the instruction-level
 // parallelism of what is otherwise one long dependent chain, and each system's factors are
@@ -568,7 +482,7 @@ __device__ __forceinline__ void solve_cplx(const Lane &L, const Jac &J, const Ld
 template <int LV> struct SysFactors { double ra[LV], rg[LV], rinv; cplx ca[LV], cg[LV], cinv; };
 
 template <int LV>
-__device__ __forceinline__ void load_sys(const LdsSlots &F, int k, SysFactors<LV> &s)
+__device__ __forceinline__ void load_sys(const FStore<LV> &F, int k, SysFactors<LV> &s)
 {
     using S = FSlots<LV>;
     const int r0 = k * S::RS, c0 = S::CB + k * S::CS;
@@ -597,7 +511,7 @@ __device__ __forceinline__ void pcr_rc_level(const Lane &L, const SysFactors<LV>
 }
 
 template <bool ROW, int LV>
-__device__ __forceinline__ void solve_rc(const Lane &L, const Jac &J, const LdsSlots &F,
+__device__ __forceinline__ void solve_rc(const Lane &L, const Jac &J, const FStore<LV> &F,
                                          double br[3], double cr[3], double ci[3])
 {
     SysFactors<LV> sT, sP, sC;
@@ -861,8 +775,9 @@ __global__ __launch_bounds__(64) void step_kernel(const StepArgs a)
     double aux[3] = {0, 0, 0};                        // y0 + h0 f0 (initial step) / error vector (refinement)
     double Q[3][3], y_old[3] = {0, 0, 0};             // dense output of the last accepted step
     Jac J;
-    __shared__ double lds_factors[FSlots<LV>::TOTAL * 64];
-    const LdsSlots F = {lds_factors + (threadIdx.x & 63)};
+    __shared__ double lds_factors[FSlots<LV>::LDS_SLOTS * 64];
+    FStore<LV> F;
+    F.base = lds_factors + (threadIdx.x & 63);
     double fac[3] = {0, 0, 0}; bool have_fac = false;
     double t_out = a.time[r];                         // ReactorState.time
     double t = 0, t_bound = 0, max_step = 0;
