@@ -25,6 +25,7 @@ logger = logging.getLogger(__name__)
 
 ST_T_RANGE, ST_SOLVER_FAILED, ST_CLAMP_PH, ST_CLAMP_CL, ST_CLAMP_T, ST_T_RANGE_POST, ST_NONFINITE = (
     1, 2, 4, 8, 16, 32, 64)
+ST_STEP_LIMIT = 128
 
 _T_RANGE_TEXT = (
     "Temperature {value}°C outside liquid water range [0.0, 100.0]°C. This indicates either:\n"
@@ -281,6 +282,11 @@ class ReactorEnsemble:
         streams, at most ``chunk_steps`` outer steps per launch (0 = one launch per call)."""
         _native.check(_native.lib().wt_ensemble_set_schedule(self._h, int(n_streams), int(chunk_steps)))
 
+    def set_step_limit(self, max_attempts: int) -> None:
+        """Stop a reactor that needs more than ``max_attempts`` Radau step attempts in one outer step
+        (status SOLVER_FAILED | STEP_LIMIT).  0 = unlimited, which is what the reference does."""
+        _native.check(_native.lib().wt_ensemble_set_step_limit(self._h, int(max_attempts)))
+
     def set_sync(self, sync_outer: bool) -> None:
         _native.check(_native.lib().wt_ensemble_set_sync(self._h, 1 if sync_outer else 0))
 
@@ -428,7 +434,9 @@ class IntegratedCSTR:
         flags = int(es.status[0])
         if flags & ST_T_RANGE:
             raise ValueError(_T_RANGE_TEXT.format(value="<zone value>"))
-        if flags & ST_SOLVER_FAILED:
+        if flags & ST_STEP_LIMIT:
+            logger.warning("ODE solver stopped: internal step-attempt limit reached (see set_step_limit)")
+        elif flags & ST_SOLVER_FAILED:
             logger.warning(_SOLVER_FAILED_TEXT)
         pre = None
         s.pH, s.chlorine, s.temperature = es.pH[0].copy(), es.chlorine[0].copy(), es.temperature[0].copy()

@@ -46,7 +46,7 @@ constexpr double MIN_FACTOR = 0.2, MAX_FACTOR = 10.0;
 
 // status bits (include/wtphys.h)
 constexpr uint32_t ST_T_RANGE = 1, ST_SOLVER_FAILED = 2, ST_CLAMP_PH = 4, ST_CLAMP_CL = 8,
-                   ST_CLAMP_T = 16, ST_T_RANGE_POST = 32, ST_NONFINITE = 64;
+                   ST_CLAMP_T = 16, ST_T_RANGE_POST = 32, ST_NONFINITE = 64, ST_STEP_LIMIT = 128;
 
 // Radau IIA / num_jac constants with the values scipy's module-level expressions
 // produce (radau.py:11-40, common.py:248-253), as exact hex literals.
@@ -94,6 +94,7 @@ struct StepArgs {
     double dt;
     int n_steps;
     int sync_outer;   // 1: the reactors of a wavefront start every outer step together
+    int step_limit;   // give up an outer step after this many step attempts (0 = never, as the reference)
 };
 
 // ---------------------------------------------------------------- lane geometry and cross-lane moves
@@ -794,6 +795,7 @@ __global__ __launch_bounds__(64) void step_kernel(const StepArgs a)
     double dH = 0, dR = 0, dK = 0; bool wrote_k = false, advanced = false;
     SolverCounters cnt = {0, 0, 0, 0, 0};
     int steps_left = a.n_steps;
+    int attempts = 0; bool limit_hit = false;   // guard against unbounded solves (sliding along a discontinuity)
     bool pend_f = false;          // f(yc) of the last accepted step has not been evaluated yet
     bool jac_after_fnew = false;  // that step also asked for a fresh Jacobian (radau.py:500,512)
     int phase = PH_OUTER_BEGIN;
@@ -868,6 +870,7 @@ __global__ __launch_bounds__(64) void step_kernel(const StepArgs a)
                 phase = PH_EXIT;
             } else {
                 if (failed) st |= ST_SOLVER_FAILED;    // reactor.py:486-487; state <- last accepted y
+                if (limit_hit) st |= ST_STEP_LIMIT;
 #pragma unroll
                 for (int q = 0; q < 3; ++q) y0[q] = yc[q];
                 advanced = true;
@@ -901,7 +904,7 @@ __global__ __launch_bounds__(64) void step_kernel(const StepArgs a)
 #pragma unroll
             for (int q = 0; q < 3; ++q) yc[q] = y0[q];
             have_fac = false; have_sol = false; have_old = false; have_lu = false; current_jac = true;
-            failed = false; pend_f = false;
+            failed = false; pend_f = false; attempts = 0; limit_hit = false;
             cnt = {0, 0, 0, 0, 0};
             if (f_valid) {
                 // f(y0) is already in f (last evaluation of the previous outer step, same y, same
@@ -921,8 +924,10 @@ __global__ __launch_bounds__(64) void step_kernel(const StepArgs a)
         }
         if (phase == PH_ATTEMPT) {
             if (!keep_h) {
-                if (h_abs_l < min_step) { failed = true; phase = PH_OUTER_END; }  // radau.py:427-428
+                if (a.step_limit > 0 && attempts >= a.step_limit) { failed = true; limit_hit = true; phase = PH_OUTER_END; }
+                else if (h_abs_l < min_step) { failed = true; phase = PH_OUTER_END; }  // radau.py:427-428
                 else {
+                    attempts++;
                     h = h_abs_l;
                     t_new = t + h;
                     if (t_new - t_bound > 0) t_new = t_bound;

@@ -56,6 +56,7 @@ struct wt_ensemble {
     // 1250 wavefronts of work no longer take two full rounds on 1024 SIMDs.
     int n_sub = 1, chunk_steps = 25;
     int sync_outer = 1;
+    int step_limit = 20000;   // attempts per outer step before a reactor is given up (reference: unlimited)
     hipStream_t sub_stream[WT_MAX_STREAMS] = {};
     hipEvent_t sub_done[WT_MAX_STREAMS] = {};
     hipEvent_t ev_fork = nullptr;
@@ -75,7 +76,7 @@ wt::StepArgs make_args(const wt_ensemble *h, double dt, int n_steps)
     a.pH = h->pH; a.Cl = h->Cl; a.T = h->T; a.time = h->time; a.flow = h->flow;
     a.dH = h->dH; a.dRho = h->dRho; a.dK = h->dK;
     a.status = h->status; a.stats = h->stats; a.wave_diag = h->wave_diag;
-    a.dt = dt; a.n_steps = n_steps; a.sync_outer = h->sync_outer;
+    a.dt = dt; a.n_steps = n_steps; a.sync_outer = h->sync_outer; a.step_limit = h->step_limit;
     return a;
 }
 
@@ -322,6 +323,14 @@ int wt_ensemble_launch_stats(wt_ensemble *h, int64_t *n_launches, double *sum_ms
     }
     *n_launches = (int64_t)(h->lt_used / 2); *sum_ms = sum; *max_ms = mx;
     h->lt_used = 0;
+    return WT_OK;
+}
+
+int wt_ensemble_set_step_limit(wt_ensemble *h, int max_attempts)
+{
+    if (!h) return fail(WT_E_ARG, "NULL handle");
+    if (max_attempts < 0) return fail(WT_E_ARG, "max_attempts must be >= 0 (0 = unlimited)");
+    h->step_limit = max_attempts;
     return WT_OK;
 }
 

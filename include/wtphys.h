@@ -60,7 +60,9 @@ enum {
     WT_ST_CLAMP_T = 16,       /* reactor.py:539-541 */
     WT_ST_T_RANGE_POST = 32,  /* ValueError out of _update_derived_state (reactor.py:522-524):
                                  state/time/H/density were updated, decay rate and clamps were not */
-    WT_ST_NONFINITE = 64
+    WT_ST_NONFINITE = 64,
+    WT_ST_STEP_LIMIT = 128    /* not a reference behaviour: the attempt limit of wt_ensemble_set_step_limit was hit;
+                                 always together with WT_ST_SOLVER_FAILED, state = last accepted y */
 };
 
 enum {
@@ -107,6 +109,13 @@ int wt_ensemble_set_schedule(wt_ensemble *h, int n_streams, int chunk_steps);
  * for the slowest of them) so that their Jacobian / factorisation / Newton work coincides.
  * Results are unaffected; it is a throughput knob. */
 int wt_ensemble_set_sync(wt_ensemble *h, int sync_outer);
+/* Guard the reference lacks.  Where the solution slides along a discontinuity of the RHS (the
+ * 8 degC density branch, spatial.py:177-189, under strong heat loss) scipy's Radau takes millions
+ * of internal steps for one outer step; the reference would grind through them for hours.  A
+ * reactor that needs more than max_attempts step attempts (accepted + rejected) in one outer step
+ * is stopped like a solver failure (WT_ST_SOLVER_FAILED | WT_ST_STEP_LIMIT).  Default 20000
+ * (a normal step needs 2-4); 0 = unlimited. */
+int wt_ensemble_set_step_limit(wt_ensemble *h, int max_attempts);
 int wt_ensemble_synchronize(wt_ensemble *h);
 
 /* ReactorState read-back (reactor.py:113-147).  Any pointer may be NULL.

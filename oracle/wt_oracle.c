@@ -29,6 +29,12 @@
 static int g_linsolve = 0;
 void wto_set_linsolve(int mode) { g_linsolve = mode; }
 
+/* Guard that the reference does not have: give up an outer step after this many step attempts
+ * (accepted + rejected + halved).  0 = unlimited = the reference's behaviour.  Mirrors
+ * wt_ensemble_set_step_limit of the HIP library so that statuses can be compared. */
+static long g_step_limit = 0;
+void wto_set_step_limit(long max_attempts) { g_step_limit = max_attempts; }
+
 /* ------------------------------------------------------------------ */
 /* RHS: IntegratedCSTR.derivatives  reactor.py:272-448                 */
 /* ------------------------------------------------------------------ */
@@ -204,6 +210,8 @@ typedef struct {
     const double *par, *bc;
     int nfev, njev, nlu, nrhs;
     int abort_status; /* non-zero => the reference would have raised */
+    long attempts;    /* step attempts of this outer step */
+    int limit_hit;
 } rctx;
 
 /* constants radau.py:11-40, computed the way the module computes them */
@@ -648,6 +656,8 @@ static int step_impl(rctx *c, radau_t *R, lu_t *L, double t_bound, double max_st
     double Z0[3][MAXM], Z[3][MAXM], scale[MAXM], y_new[MAXM], error[MAXM], ZE[MAXM], tmp[MAXM];
     double h = 0, t_new = 0, error_norm = 0, safety = 0, rate = 0; int n_iter = 0, have_rate = 0;
     while (!step_accepted) {
+        if (g_step_limit > 0 && c->attempts >= g_step_limit) { c->limit_hit = 1; return 0; }
+        c->attempts++;
         if (h_abs < min_step) return 0;
         h = h_abs * 1.0;
         t_new = t + h;
@@ -781,6 +791,7 @@ int wto_step(int n, const double *par, const double *bc, double dt,
     if (st) { st->nfev = c.nfev; st->njev = c.njev; st->nlu = c.nlu; st->nrhs_total = c.nrhs; }
     if (aborted) return status | (c.abort_status & WTO_ST_T_RANGE ? WTO_ST_T_RANGE : WTO_ST_NONFINITE);
     if (solver_failed) status |= WTO_ST_SOLVER_FAILED;
+    if (c.limit_hit) status |= WTO_ST_STEP_LIMIT;
 
     /* reactor.py:493-501: state <- last accepted y; time += dt */
     memcpy(y, R.y, sizeof(double) * m);

@@ -54,7 +54,8 @@ enum {
     WTO_ST_CLAMP_CL = 8,      /* reactor.py:534-536 */
     WTO_ST_CLAMP_T = 16,      /* reactor.py:539-541 */
     WTO_ST_T_RANGE_POST = 32, /* ValueError from _update_derived_state reactor.py:522-524 */
-    WTO_ST_NONFINITE = 64
+    WTO_ST_NONFINITE = 64,
+    WTO_ST_STEP_LIMIT = 128   /* guard (not in the reference): attempt limit of wto_set_step_limit hit */
 };
 
 typedef struct {
@@ -70,6 +71,9 @@ typedef struct {
 /* linear-solve flavour: 0 = dense partial-pivot LU (what scipy does),
  * 1 = block-triangular tridiagonal solve (what the HIP kernel does). */
 void wto_set_linsolve(int mode);
+/* 0 = unlimited (reference behaviour); otherwise stop an outer step after that many step attempts
+ * with WTO_ST_SOLVER_FAILED | WTO_ST_STEP_LIMIT, state = last accepted y, as a solver failure. */
+void wto_set_step_limit(long max_attempts);
 
 /* derivatives(t, y, boundary): reactor.py:272-448.  y = [pH.., Cl.., T..].
  * returns 0, or WTO_ST_T_RANGE if any T outside [0,100] (reference raises). */

@@ -20,6 +20,7 @@ _LIB_PATH = os.path.join(_HERE, "libwtoracle.so")
 NP = 16
 NB = 10
 ST_T_RANGE, ST_SOLVER_FAILED, ST_CLAMP_PH, ST_CLAMP_CL, ST_CLAMP_T, ST_T_RANGE_POST, ST_NONFINITE = 1, 2, 4, 8, 16, 32, 64
+ST_STEP_LIMIT = 128
 
 
 class Stats(C.Structure):
@@ -58,6 +59,7 @@ def lib():
         L.wto_calculate_pH.argtypes = [C.c_double] * 7 + [C.c_int, dp, C.POINTER(C.c_int)]
         L.wto_calculate_pH.restype = C.c_int
         L.wto_set_linsolve.argtypes = [C.c_int]
+        L.wto_set_step_limit.argtypes = [C.c_long]
         _lib = L
     return _lib
 
@@ -69,6 +71,11 @@ def _dp(a: np.ndarray):
 def set_linsolve(mode: int) -> None:
     """0 = dense partial-pivot LU (scipy's), 1 = block-triangular tridiagonal (the HIP kernel's)."""
     lib().wto_set_linsolve(int(mode))
+
+
+def set_step_limit(max_attempts: int) -> None:
+    """0 = unlimited (the reference); mirrors ReactorEnsemble.set_step_limit."""
+    lib().wto_set_step_limit(int(max_attempts))
 
 
 def rhs(n: int, par: np.ndarray, bc: np.ndarray, y: np.ndarray) -> Tuple[np.ndarray, int]:
