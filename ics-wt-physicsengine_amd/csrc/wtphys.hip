@@ -56,7 +56,7 @@ struct wt_ensemble {
     // 1250 wavefronts of work no longer take two full rounds on 1024 SIMDs.
     int n_sub = 1, chunk_steps = 25;
     int sync_outer = 1;
-    int step_limit = 20000;   // attempts per outer step before a reactor is given up (reference: unlimited)
+    int step_limit = 2000;    // attempts per outer step before a reactor is given up (reference: unlimited)
     hipStream_t sub_stream[WT_MAX_STREAMS] = {};
     hipEvent_t sub_done[WT_MAX_STREAMS] = {};
     hipEvent_t ev_fork = nullptr;

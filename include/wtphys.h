@@ -113,8 +113,8 @@ int wt_ensemble_set_sync(wt_ensemble *h, int sync_outer);
  * 8 degC density branch, spatial.py:177-189, under strong heat loss) scipy's Radau takes millions
  * of internal steps for one outer step; the reference would grind through them for hours.  A
  * reactor that needs more than max_attempts step attempts (accepted + rejected) in one outer step
- * is stopped like a solver failure (WT_ST_SOLVER_FAILED | WT_ST_STEP_LIMIT).  Default 20000
- * (a normal step needs 2-4); 0 = unlimited. */
+ * is stopped like a solver failure (WT_ST_SOLVER_FAILED | WT_ST_STEP_LIMIT).  Default 2000
+ * (a normal step needs 2-4, a hard one a few dozen); 0 = unlimited. */
 int wt_ensemble_set_step_limit(wt_ensemble *h, int max_attempts);
 int wt_ensemble_synchronize(wt_ensemble *h);
 
