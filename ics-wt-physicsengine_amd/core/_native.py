@@ -89,6 +89,10 @@ def lib():
     L.wt_ensemble_timer_start.argtypes = [vp]
     L.wt_ensemble_timer_stop.argtypes = [vp, C.POINTER(C.c_float)]
     L.wt_selftest_shuffles.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int)]
+    u8p, fp = C.POINTER(C.c_uint8), C.POINTER(C.c_float)
+    L.wt_ensemble_sensors_enable.argtypes = [vp, C.c_uint64, C.c_int64, dp, dp, dp, C.c_int]
+    L.wt_ensemble_sensors_get.argtypes = [vp, fp, u8p, u8p]
+    L.wt_ensemble_sensors_history.argtypes = [vp, fp, u8p, u8p, i32p]
     L.wt_ensemble_wave_diag.argtypes = [vp, C.POINTER(C.c_int64), C.c_int64, C.POINTER(C.c_int64)]
     L.wt_ensemble_size.argtypes = [vp]
     L.wt_ensemble_size.restype = C.c_int64
@@ -99,7 +103,8 @@ def lib():
                  "wt_ensemble_get_state", "wt_ensemble_get_derived", "wt_ensemble_get_status",
                  "wt_ensemble_clear_status", "wt_ensemble_get_stats", "wt_ensemble_rhs",
                  "wt_ensemble_export_state_device", "wt_ensemble_set_stream", "wt_ensemble_timer_start",
-                 "wt_ensemble_timer_stop", "wt_ensemble_zones", "wt_ph_solve", "wt_selftest_shuffles", "wt_ensemble_wave_diag", "wt_ensemble_set_schedule", "wt_ensemble_set_sync", "wt_ensemble_set_step_limit", "wt_ensemble_launch_timing", "wt_ensemble_launch_stats"):
+                 "wt_ensemble_timer_stop", "wt_ensemble_zones", "wt_ph_solve", "wt_selftest_shuffles", "wt_ensemble_wave_diag", "wt_ensemble_set_schedule", "wt_ensemble_set_sync", "wt_ensemble_set_step_limit", "wt_ensemble_sensors_enable", "wt_ensemble_sensors_get",
+                 "wt_ensemble_sensors_history", "wt_ensemble_launch_timing", "wt_ensemble_launch_stats"):
         getattr(L, name).restype = C.c_int
     if L.wt_abi_version() != 1:
         raise ImportError("libwtphys.so ABI version mismatch; rebuild it")

@@ -339,6 +339,40 @@ class ReactorEnsemble:
                                                    fl.ctypes.data_as(C.POINTER(C.c_uint32))))
         return out[0], out[1], out[2], fl
 
+    # -- fused sensor suite (NEXT-1)
+    SENSOR_NAMES = ("pH_inlet", "pH_outlet", "chlorine_inlet", "chlorine_outlet", "flow_main", "temp_inlet", "temp_outlet")
+
+    def enable_sensors(self, seed: int = 0x5EED, reactor_base: int = 0, history: int = 0) -> None:
+        """Attach the reference's seven-sensor suite (``create_realistic_sensor_suite`` +
+        ``initialize_sensors``) to every reactor, calibrated now; every later outer step is followed by
+        ``read_all_sensors`` on the device.  ``history`` > 0 keeps that many reads per sensor."""
+        c = self.columns
+        d = ReactorConfiguration()
+        col = lambda k: np.ascontiguousarray(np.broadcast_to(np.asarray(c.get(k, getattr(d, k)), dtype=np.float64), (self.n_reactors,)))
+        _native.check(_native.lib().wt_ensemble_sensors_enable(
+            self._h, C.c_uint64(int(seed) & 0xFFFFFFFFFFFFFFFF), int(reactor_base), _native.dptr(col("flow_rate")),
+            _native.dptr(col("initial_chlorine")), _native.dptr(col("temperature")), int(history)))
+        self._sensor_history = int(history)
+
+    def sensor_readings(self):
+        """(values float32 (7, N), status uint8 (7, N), fault uint8 (7, N)) of the last read."""
+        N = self.n_reactors
+        v = np.empty((7, N), dtype=np.float32); s = np.empty((7, N), dtype=np.uint8); f = np.empty((7, N), dtype=np.uint8)
+        u8 = C.POINTER(C.c_uint8)
+        _native.check(_native.lib().wt_ensemble_sensors_get(self._h, v.ctypes.data_as(C.POINTER(C.c_float)),
+                                                            s.ctypes.data_as(u8), f.ctypes.data_as(u8)))
+        return v, s, f
+
+    def sensor_history(self):
+        """(values (H, 7, N), status, fault, reads per reactor (N,)) recorded since enable_sensors(history=H)."""
+        N, H = self.n_reactors, self._sensor_history
+        v = np.empty((H, 7, N), dtype=np.float32); s = np.empty((H, 7, N), dtype=np.uint8); f = np.empty((H, 7, N), dtype=np.uint8)
+        n = np.zeros(N, dtype=np.int32)
+        u8 = C.POINTER(C.c_uint8)
+        _native.check(_native.lib().wt_ensemble_sensors_history(self._h, v.ctypes.data_as(C.POINTER(C.c_float)), s.ctypes.data_as(u8),
+                                                                f.ctypes.data_as(u8), n.ctypes.data_as(C.POINTER(C.c_int32))))
+        return v, s, f, n
+
     def wave_diag(self) -> Optional[np.ndarray]:
         """Per-wavefront diagnostics of the last launch, (n_waves, 8) int64:
         loop trips, Newton trips, shader clocks, 100 MHz wall ticks, factorize / num_jac /

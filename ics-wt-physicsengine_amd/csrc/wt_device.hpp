@@ -95,6 +95,10 @@ struct StepArgs {
     int n_steps;
     int sync_outer;   // 1: the reactors of a wavefront start every outer step together
     int step_limit;   // give up an outer step after this many step attempts (0 = never, as the reference)
+    // optional taps for the sensor suite (wt_sensors.hpp): what the sensors look at after every outer step
+    float *taps;         // [n_steps][7][N]: pH0, pHN, Cl0, ClN, T0, TN, flow  (nullptr = off)
+    int32_t *tap_count;  // [N] outer steps completed in this launch
+    double *tap_time;    // [N] ReactorState.time of the last tap
 };
 
 // ---------------------------------------------------------------- lane geometry and cross-lane moves
@@ -766,7 +770,7 @@ __global__ __launch_bounds__(64) void step_kernel(const StepArgs a)
     const int64_t idx = r * a.n + L.z;
     uint32_t st = a.status[r];
     // a reactor whose last step raised stays frozen until the host rewrites its state
-    if (st & (ST_T_RANGE | ST_T_RANGE_POST)) return;
+    if (st & (ST_T_RANGE | ST_T_RANGE_POST)) { if (a.tap_count && L.z == 0) a.tap_count[r] = 0; return; }
     RK k; load_reactor(a.par, a.bc, a.N, r, a.n, k); mask_reactor_for_lane(L, k);
 
     // ---- per-reactor state (segment-uniform scalars are replicated in every lane)
@@ -890,6 +894,15 @@ __global__ __launch_bounds__(64) void step_kernel(const StepArgs a)
                     if (seg_any(L, !(isfinite(y0[0]) && isfinite(y0[1]) && isfinite(y0[2])))) st |= ST_NONFINITE;
                     // f(y) of the last accepted point is f0 of the next outer step when nothing touched y
                     f_valid = f_valid && !clamped && !failed;
+                    if (a.taps) {   // what read_all_sensors sees after this step (__main__.py:403-410)
+                        float *tp = a.taps + ((int64_t)(a.n_steps - steps_left) * 7) * a.N + r;
+                        if (!L.has_lo) {
+                            tp[0 * a.N] = (float)y0[SPH]; tp[2 * a.N] = (float)y0[SCL]; tp[4 * a.N] = (float)y0[STT];
+                            tp[6 * a.N] = (float)(a.bc[0 * a.N + r] + a.bc[4 * a.N + r] + a.bc[6 * a.N + r]);
+                            a.tap_time[r] = t_out;
+                        }
+                        if (!L.has_hi) { tp[1 * a.N] = (float)y0[SPH]; tp[3 * a.N] = (float)y0[SCL]; tp[5 * a.N] = (float)y0[STT]; }
+                    }
                     steps_left--;
                     phase = (steps_left > 0) ? PH_OUTER_BEGIN : PH_EXIT;
                 }
@@ -1169,6 +1182,7 @@ __global__ __launch_bounds__(64) void step_kernel(const StepArgs a)
             a.flow[r] = a.bc[0 * a.N + r] + a.bc[4 * a.N + r] + a.bc[6 * a.N + r];
         }
         a.status[r] = st;
+        if (a.tap_count) a.tap_count[r] = a.n_steps - steps_left;
         if (a.stats) {
             int32_t *o = a.stats + r * 5;
             o[0] = cnt.nfev; o[1] = cnt.njev; o[2] = cnt.nlu; o[3] = cnt.nsteps; o[4] = cnt.nrej;

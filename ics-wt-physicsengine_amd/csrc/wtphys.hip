@@ -2,6 +2,7 @@
 // Owns device memory behind an opaque handle, uploads the SoA constant / boundary
 // blocks, launches the gfx950 kernels of wt_device.hpp on the handle's stream.
 #include "wt_device.hpp"
+#include "wt_sensors.hpp"
 #include "../../include/wtphys.h"
 
 #include <cmath>
@@ -60,6 +61,14 @@ struct wt_ensemble {
     hipStream_t sub_stream[WT_MAX_STREAMS] = {};
     hipEvent_t sub_done[WT_MAX_STREAMS] = {};
     hipEvent_t ev_fork = nullptr;
+    // optional fused sensor suite (wt_sensors.hpp)
+    bool sensors_on = false;
+    uint64_t sens_seed = 0; int64_t sens_reactor_base = 0;
+    float *s_fs = nullptr, *s_full_scale = nullptr, *s_ring_t = nullptr, *s_ring_v = nullptr, *s_out_value = nullptr, *s_hist_value = nullptr;
+    double *s_ds = nullptr, *s_t_enable = nullptr, *s_tap_time = nullptr;
+    int32_t *s_is = nullptr, *s_ring_head = nullptr, *s_ring_cnt = nullptr, *s_hist_pos = nullptr, *s_tap_count = nullptr;
+    uint8_t *s_out_status = nullptr, *s_out_fault = nullptr, *s_hist_status = nullptr, *s_hist_fault = nullptr;
+    float *s_taps = nullptr; int s_taps_steps = 0; int s_hist_cap = 0;
     // optional per-launch HIP-event timing (bench.py roofline accounting)
     bool time_launches = false;
     std::vector<hipEvent_t> lt_pool;   // start/stop pairs
@@ -77,6 +86,8 @@ wt::StepArgs make_args(const wt_ensemble *h, double dt, int n_steps)
     a.dH = h->dH; a.dRho = h->dRho; a.dK = h->dK;
     a.status = h->status; a.stats = h->stats; a.wave_diag = h->wave_diag;
     a.dt = dt; a.n_steps = n_steps; a.sync_outer = h->sync_outer; a.step_limit = h->step_limit;
+    a.taps = h->sensors_on ? h->s_taps : nullptr; a.tap_count = h->sensors_on ? h->s_tap_count : nullptr;
+    a.tap_time = h->sensors_on ? h->s_tap_time : nullptr;
     return a;
 }
 
@@ -84,9 +95,24 @@ bool row_mode(int n) { return n == 2 || n == 4 || n == 8 || n == 16; }
 
 void launch_step_raw(const wt_ensemble *h, const wt::StepArgs &a, hipStream_t stream);
 
+void launch_sensors(wt_ensemble *h, const wt::StepArgs &a, hipStream_t stream)
+{
+    wts::SensorArgs s;
+    s.N = h->N; s.r0 = a.r0; s.r1 = a.r1; s.reactor_base = h->sens_reactor_base;
+    s.seed_lo = (uint32_t)(h->sens_seed & 0xffffffffu); s.seed_hi = (uint32_t)(h->sens_seed >> 32);
+    s.n_steps = a.n_steps; s.dt = a.dt; s.taps = h->s_taps; s.tap_count = h->s_tap_count; s.time_end = h->s_tap_time; s.t_enable = h->s_t_enable;
+    s.fs = h->s_fs; s.ds = h->s_ds; s.is = h->s_is; s.full_scale = h->s_full_scale;
+    s.ring_t = h->s_ring_t; s.ring_v = h->s_ring_v; s.ring_head = h->s_ring_head; s.ring_cnt = h->s_ring_cnt;
+    s.out_value = h->s_out_value; s.out_status = h->s_out_status; s.out_fault = h->s_out_fault;
+    s.hist_value = h->s_hist_value; s.hist_status = h->s_hist_status; s.hist_fault = h->s_hist_fault;
+    s.hist_cap = h->s_hist_cap; s.hist_pos = h->s_hist_pos;
+    const unsigned grid = (unsigned)((a.r1 - a.r0 + 63) / 64);
+    hipLaunchKernelGGL(wts::sensor_suite_kernel, dim3(grid), dim3(64), 0, stream, s);
+}
+
 void launch_step(wt_ensemble *h, const wt::StepArgs &a, hipStream_t stream)
 {
-    if (!h->time_launches) { launch_step_raw(h, a, stream); return; }
+    if (!h->time_launches) { launch_step_raw(h, a, stream); if (h->sensors_on) launch_sensors(h, a, stream); return; }
     if (h->lt_used + 2 > h->lt_pool.size()) {
         for (int i = 0; i < 2; ++i) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) { launch_step_raw(h, a, stream); return; } h->lt_pool.push_back(e); }
     }
@@ -94,6 +120,7 @@ void launch_step(wt_ensemble *h, const wt::StepArgs &a, hipStream_t stream)
     launch_step_raw(h, a, stream);
     (void)hipEventRecord(h->lt_pool[h->lt_used + 1], stream);
     h->lt_used += 2;
+    if (h->sensors_on) launch_sensors(h, a, stream);
 }
 
 void launch_step_raw(const wt_ensemble *h, const wt::StepArgs &a, hipStream_t stream)
@@ -202,6 +229,10 @@ int wt_ensemble_destroy(wt_ensemble *h)
         if (h->sub_stream[s]) { (void)hipStreamSynchronize(h->sub_stream[s]); (void)hipStreamDestroy(h->sub_stream[s]); }
         if (h->sub_done[s]) (void)hipEventDestroy(h->sub_done[s]);
     }
+    void *sp[] = {h->s_fs, h->s_full_scale, h->s_ring_t, h->s_ring_v, h->s_out_value, h->s_hist_value, h->s_ds, h->s_t_enable, h->s_is,
+                  h->s_ring_head, h->s_ring_cnt, h->s_hist_pos, h->s_tap_count, h->s_tap_time, h->s_out_status, h->s_out_fault, h->s_hist_status,
+                  h->s_hist_fault, h->s_taps};
+    for (void *p : sp) if (p) (void)hipFree(p);
     for (hipEvent_t e : h->lt_pool) (void)hipEventDestroy(e);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -266,6 +297,16 @@ int wt_ensemble_step(wt_ensemble *h, double dt, int n_steps, int fused)
     if (n_steps == 0) return WT_OK;
     HIP_TRY(hipSetDevice(h->device));
     const int chunk = fused ? (h->chunk_steps > 0 ? h->chunk_steps : n_steps) : 1;
+    if (h->sensors_on) {   // tap buffer for the longest launch of this call
+        const int need = chunk < n_steps ? chunk : n_steps;
+        if (need > h->s_taps_steps) {
+            HIP_TRY(hipStreamSynchronize(h->stream));
+            if (h->s_taps) (void)hipFree(h->s_taps);
+            h->s_taps = nullptr;
+            HIP_TRY(hipMalloc((void **)&h->s_taps, sizeof(float) * (size_t)need * 7 * (size_t)h->N));
+            h->s_taps_steps = need;
+        }
+    }
     const int S = h->n_sub;
     if (S <= 1) {
         for (int done = 0; done < n_steps; done += chunk) {
@@ -323,6 +364,91 @@ int wt_ensemble_launch_stats(wt_ensemble *h, int64_t *n_launches, double *sum_ms
     }
     *n_launches = (int64_t)(h->lt_used / 2); *sum_ms = sum; *max_ms = mx;
     h->lt_used = 0;
+    return WT_OK;
+}
+
+int wt_ensemble_sensors_enable(wt_ensemble *h, uint64_t seed, int64_t reactor_base, const double *cfg_flow,
+                               const double *cfg_chlorine, const double *cfg_temperature, int history_capacity)
+{
+    if (!h || !cfg_flow || !cfg_chlorine || !cfg_temperature) return fail(WT_E_ARG, "NULL argument");
+    if (history_capacity < 0) return fail(WT_E_ARG, "history_capacity must be >= 0");
+    if (h->sensors_on) return fail(WT_E_STATE, "sensor suite already enabled");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    const size_t N = (size_t)h->N;
+    double *cfg = nullptr;
+    HIP_TRY(hipMalloc((void **)&cfg, sizeof(double) * 3 * N));
+#define SALLOC(ptr, bytes) do { if (hipMalloc((void **)&(ptr), (bytes)) != hipSuccess) { (void)hipFree(cfg); return fail(WT_E_HIP, "hipMalloc (sensors) failed"); } } while (0)
+    SALLOC(h->s_fs, sizeof(float) * wts::NSENS * wts::NF * N);
+    SALLOC(h->s_ds, sizeof(double) * wts::NSENS * wts::ND * N);
+    SALLOC(h->s_is, sizeof(int32_t) * wts::NSENS * wts::NI * N);
+    SALLOC(h->s_full_scale, sizeof(float) * N);
+    SALLOC(h->s_ring_t, sizeof(float) * 2 * wts::RING * N);
+    SALLOC(h->s_ring_v, sizeof(float) * 2 * wts::RING * N);
+    SALLOC(h->s_ring_head, sizeof(int32_t) * 2 * N);
+    SALLOC(h->s_ring_cnt, sizeof(int32_t) * 2 * N);
+    SALLOC(h->s_out_value, sizeof(float) * wts::NSENS * N);
+    SALLOC(h->s_out_status, wts::NSENS * N);
+    SALLOC(h->s_out_fault, wts::NSENS * N);
+    SALLOC(h->s_tap_count, sizeof(int32_t) * N);
+    SALLOC(h->s_t_enable, sizeof(double) * N);
+    SALLOC(h->s_tap_time, sizeof(double) * N);
+    h->s_hist_cap = history_capacity;
+    if (history_capacity > 0) {
+        SALLOC(h->s_hist_value, sizeof(float) * (size_t)history_capacity * wts::NSENS * N);
+        SALLOC(h->s_hist_status, (size_t)history_capacity * wts::NSENS * N);
+        SALLOC(h->s_hist_fault, (size_t)history_capacity * wts::NSENS * N);
+        SALLOC(h->s_hist_pos, sizeof(int32_t) * N);
+    }
+#undef SALLOC
+    hipError_t e = hipMemcpy(cfg, cfg_flow, sizeof(double) * N, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(cfg + N, cfg_chlorine, sizeof(double) * N, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(cfg + 2 * N, cfg_temperature, sizeof(double) * N, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpyAsync(h->s_t_enable, h->time, sizeof(double) * N, hipMemcpyDeviceToDevice, h->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(h->s_ring_t, 0, sizeof(float) * 2 * wts::RING * N, h->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(h->s_ring_v, 0, sizeof(float) * 2 * wts::RING * N, h->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(h->s_tap_count, 0, sizeof(int32_t) * N, h->stream);
+    if (e == hipSuccess) {
+        wts::SensorInitArgs a;
+        a.N = h->N; a.cfg_flow = cfg; a.cfg_cl = cfg + N; a.cfg_temp = cfg + 2 * N;
+        a.fs = h->s_fs; a.ds = h->s_ds; a.is = h->s_is; a.full_scale = h->s_full_scale;
+        a.ring_head = h->s_ring_head; a.ring_cnt = h->s_ring_cnt;
+        a.out_value = h->s_out_value; a.out_status = h->s_out_status; a.out_fault = h->s_out_fault; a.hist_pos = h->s_hist_pos;
+        hipLaunchKernelGGL(wts::sensor_init_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, h->stream, a);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    (void)hipFree(cfg);
+    if (e != hipSuccess) return fail(WT_E_HIP, std::string("sensors_enable: ") + hipGetErrorString(e));
+    h->sens_seed = seed; h->sens_reactor_base = reactor_base;
+    h->sensors_on = true;
+    return WT_OK;
+}
+
+int wt_ensemble_sensors_get(wt_ensemble *h, float *values, uint8_t *status, uint8_t *fault)
+{
+    if (!h) return fail(WT_E_ARG, "NULL handle");
+    if (!h->sensors_on) return fail(WT_E_STATE, "sensor suite not enabled");
+    HIP_TRY(hipSetDevice(h->device));
+    const size_t cnt = (size_t)wts::NSENS * h->N;
+    if (values) HIP_TRY(hipMemcpyAsync(values, h->s_out_value, sizeof(float) * cnt, hipMemcpyDeviceToHost, h->stream));
+    if (status) HIP_TRY(hipMemcpyAsync(status, h->s_out_status, cnt, hipMemcpyDeviceToHost, h->stream));
+    if (fault) HIP_TRY(hipMemcpyAsync(fault, h->s_out_fault, cnt, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return WT_OK;
+}
+
+int wt_ensemble_sensors_history(wt_ensemble *h, float *values, uint8_t *status, uint8_t *fault, int32_t *n_filled)
+{
+    if (!h) return fail(WT_E_ARG, "NULL handle");
+    if (!h->sensors_on || h->s_hist_cap <= 0) return fail(WT_E_STATE, "sensor history not enabled");
+    HIP_TRY(hipSetDevice(h->device));
+    const size_t cnt = (size_t)h->s_hist_cap * wts::NSENS * h->N;
+    if (values) HIP_TRY(hipMemcpyAsync(values, h->s_hist_value, sizeof(float) * cnt, hipMemcpyDeviceToHost, h->stream));
+    if (status) HIP_TRY(hipMemcpyAsync(status, h->s_hist_status, cnt, hipMemcpyDeviceToHost, h->stream));
+    if (fault) HIP_TRY(hipMemcpyAsync(fault, h->s_hist_fault, cnt, hipMemcpyDeviceToHost, h->stream));
+    if (n_filled) HIP_TRY(hipMemcpyAsync(n_filled, h->s_hist_pos, sizeof(int32_t) * h->N, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
     return WT_OK;
 }
 

@@ -152,6 +152,23 @@ int wt_ensemble_launch_stats(wt_ensemble *h, int64_t *n_launches, double *sum_ms
 int wt_ensemble_timer_start(wt_ensemble *h);
 int wt_ensemble_timer_stop(wt_ensemble *h, float *elapsed_ms /* synchronises */);
 
+/* ---- fused sensor suite (SURVEY.md section 8(f) NEXT-1, BASELINE config 5; fp32 signal path) ----
+ * create_realistic_sensor_suite + initialize_sensors (sensors/__init__.py:41-120, __main__.py:84-118) for
+ * every reactor: pH inlet/outlet, chlorine amperometric inlet / DPD outlet, magnetic flow, RTD inlet/outlet,
+ * calibrated at the current ensemble time.  From then on every outer step of wt_ensemble_step is followed
+ * by read_all_sensors (__main__.py:121-163) on the device.  Randomness: Philox4x32-10, key = seed,
+ * counter = (reactor_base + reactor, sensor, draw index).  cfg_* are host arrays [N] of
+ * ReactorConfiguration.flow_rate / initial_chlorine / temperature.  history_capacity > 0 keeps the first
+ * that many reads of every sensor on the device (tests, replay). */
+#define WT_N_SENSORS 7  /* order: pH_inlet, pH_outlet, chlorine_inlet, chlorine_outlet, flow_main, temp_inlet, temp_outlet */
+int wt_ensemble_sensors_enable(wt_ensemble *h, uint64_t seed, int64_t reactor_base, const double *cfg_flow,
+                               const double *cfg_chlorine, const double *cfg_temperature, int history_capacity);
+/* last SensorReading.value / status / fault of every sensor: [WT_N_SENSORS][N]; status and fault use the
+ * declaration order of SensorStatus / SensorFault (sensors/base_sensor.py:49-75). */
+int wt_ensemble_sensors_get(wt_ensemble *h, float *values, uint8_t *status, uint8_t *fault);
+/* recorded reads [history_capacity][WT_N_SENSORS][N] and the number of reads taken per reactor [N] */
+int wt_ensemble_sensors_history(wt_ensemble *h, float *values, uint8_t *status, uint8_t *fault, int32_t *n_filled);
+
 /* Self-test of the kernel's cross-lane primitives (DPP row / wave shifts, segment
  * sums) against ds_bpermute for a given zone count; *mismatches must come back 0. */
 int wt_selftest_shuffles(int device, int n_zones, int *mismatches);
