@@ -84,6 +84,8 @@ def main() -> int:
                     help="outer steps per kernel launch (1 = one launch per outer step)")
     ap.add_argument("--streams", type=int, default=0,
                     help="reactor ranges / HIP streams per GPU (0 = library default: min(4, wavefronts/64))")
+    ap.add_argument("--sensors", action="store_true",
+                    help="BASELINE config 5: also run the fused fp32 sensor suite (7 readings per reactor per step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-reactors", type=int, default=4096)
     ap.add_argument("--cpu-sample-steps", type=int, default=100)
@@ -115,6 +117,8 @@ def main() -> int:
     cols, bc = wt.make_ensemble(N, start=rank * N)  # every rank owns a distinct slice
     ens = wt.ReactorEnsemble(cols, n_zones=n, device=local_rank)
     ens.set_boundary(bc)
+    if args.sensors:
+        ens.enable_sensors(seed=0x5EED5EED1234, reactor_base=rank * N)
 
     def barrier():
         ens.synchronize()
@@ -196,7 +200,8 @@ def main() -> int:
             "data": "synthetic",
             "config": {
                 "workload": f"{N}-reactor x {n}-zone ensemble per GPU, dt=1 s, fp64, "
-                            f"{args.chunk} outer step(s) per launch, {n_streams} reactor range(s)/stream(s)",
+                            f"{args.chunk} outer step(s) per launch, {n_streams} reactor range(s)/stream(s)"
+                            + (" + fused fp32 sensor suite" if args.sensors else ""),
                 "reactors_per_gpu": N, "zones": n, "dt_s": 1.0,
                 "sharding": f"instance-parallel x{world}, final RCCL all_gather only",
             },
@@ -219,6 +224,9 @@ def main() -> int:
                 "note": "path is fp64-VALU/latency bound (adaptive implicit solve per reactor), not HBM bound; "
                         "see DESIGN.md roofline section",
             },
+            "sensors": ({"suite": "7 sensors/reactor (pH in/out, Cl amperometric/DPD, magnetic flow, RTD in/out), fp32, "
+                                  "one read per outer step, Philox4x32-10 streams",
+                         "readings_per_s": world * N * 7 * args.steps / elapsed} if args.sensors else None),
             "final_gather_ms": gather_ms,
             "flagged_reactors": int(flagged.item()),
             "state_checksum": checksum,

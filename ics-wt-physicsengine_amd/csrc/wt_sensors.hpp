@@ -13,10 +13,10 @@
 //   FlowSensor.read            sensors/flow_sensor.py:125-219     (magnetic)
 //   TemperatureSensor.read     sensors/temperature_sensor.py:110-171 (RTD Pt100)
 //
-// Mapping: one thread per reactor (the seven reads of a step are sequential by construction: two of
-// them communicate through the shared delay lines), structure-of-arrays state so that lane r of a
-// wavefront touches word r of every state row -- the kernel is a byte mover, bound by HBM/L2
-// bandwidth.  Signal path in fp32 (config 5); time and the slow ageing accumulators in fp64.
+// Mapping: one thread per (reactor, sensor group) -- the suite splits into five groups that do not
+// interact (two of them hold the two sensors that share a delay line) -- structure-of-arrays state so
+// that lane r of a wavefront touches word r of every state row; the kernel is a byte mover, bound by
+// HBM/L2 bandwidth.  Signal path in fp32 (config 5); time and the slow ageing accumulators in fp64.
 // Input: per-step "taps" (pH, Cl, T of zones 0 and n-1, flow) written by the physics kernel for the
 // steps of one launch, so the suite sees every outer step although the physics keeps its state in
 // registers across them.
@@ -62,13 +62,13 @@ struct SensorArgs {
     int32_t *is;           // [NSENS][NI][N]
     float *full_scale;     // [N] flow sensor range
     float *ring_t, *ring_v; // [2][RING][N]
-    int32_t *ring_head, *ring_cnt; // [2][N]
+    int32_t *ring_push, *ring_cursor; // [2][N] appends so far; push index of the last sample returned
     float *out_value;      // [NSENS][N] last reading
     uint8_t *out_status, *out_fault; // [NSENS][N]
     float *hist_value;     // optional [hist_cap][NSENS][N]
     uint8_t *hist_status, *hist_fault;
     int hist_cap;
-    int32_t *hist_pos;     // [N] next history slot
+    int32_t *hist_pos;     // [NGROUP][N] next history slot (one copy per sensor group, all equal)
 };
 
 // ---------------------------------------------------------------- Philox4x32-10
@@ -121,287 +121,246 @@ __device__ __forceinline__ SensorSpec spec_of(int i, float fs)
 // vibration 0.1 <= 0.2), so they draw nothing; ambient temperature 30 degC enters the RTD stem error.
 constexpr float AMBIENT_T = 30.0f;
 
-__global__ __launch_bounds__(64) void sensor_suite_kernel(const SensorArgs a)
+// Sensors only interact through the two sample lines, so a reactor's suite splits into five independent
+// groups -- {pH_inlet, temp_inlet} (inlet line), {pH_outlet, temp_outlet} (outlet line), Cl_inlet,
+// Cl_outlet, flow -- and one thread runs one group of one reactor over the steps of a launch with the
+// group's state in registers.  blockIdx.y = group, so a wavefront executes one code path.
+constexpr int NGROUP = 5;
+
+struct SState {
+    float current, supply, cal_offset, last_value;
+    double cal_time, power_on, last_t, prev_t, slow0, slow1, slow2;
+    int status, fault, hist_n;
+    Rng rng;
+};
+
+__device__ __forceinline__ SState load_state(const SensorArgs &a, int i, int64_t r)
 {
-    const int64_t r = a.r0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= a.r1) return;
+    const int64_t N = a.N;
+    const float *F = a.fs + ((int64_t)i * NF) * N + r; const double *D = a.ds + ((int64_t)i * ND) * N + r;
+    const int32_t *I = a.is + ((int64_t)i * NI) * N + r;
+    SState s;
+    s.current = F[F_CURRENT * N]; s.supply = F[F_SUPPLY * N]; s.cal_offset = F[F_CAL_OFFSET * N]; s.last_value = F[F_LAST_VALUE * N];
+    s.cal_time = D[D_CAL_TIME * N]; s.power_on = D[D_POWER_ON * N]; s.last_t = D[D_LAST_T * N]; s.prev_t = D[D_PREV_T * N];
+    s.slow0 = D[D_SLOW0 * N]; s.slow1 = D[D_SLOW1 * N]; s.slow2 = D[D_SLOW2 * N];
+    s.status = I[I_STATUS * N]; s.fault = I[I_FAULT * N]; s.hist_n = I[I_HIST_N * N];
+    s.rng = {(uint32_t)(a.reactor_base + r), (uint32_t)i, (uint32_t)I[I_DRAWS * N], a.seed_lo, a.seed_hi};
+    return s;
+}
+
+__device__ __forceinline__ void store_state(const SensorArgs &a, int i, int64_t r, const SState &s)
+{
+    const int64_t N = a.N;
+    float *F = a.fs + ((int64_t)i * NF) * N + r; double *D = a.ds + ((int64_t)i * ND) * N + r; int32_t *I = a.is + ((int64_t)i * NI) * N + r;
+    F[F_CURRENT * N] = s.current; F[F_SUPPLY * N] = s.supply; F[F_LAST_VALUE * N] = s.last_value;
+    D[D_LAST_T * N] = s.last_t; D[D_PREV_T * N] = s.prev_t; D[D_SLOW0 * N] = s.slow0; D[D_SLOW1 * N] = s.slow1; D[D_SLOW2 * N] = s.slow2;
+    I[I_STATUS * N] = s.status; I[I_FAULT * N] = s.fault; I[I_HIST_N * N] = s.hist_n; I[I_DRAWS * N] = (int32_t)s.rng.draws;
+}
+
+// SampleLine.transport_sample base_sensor.py:177-216: append (t, value) to a deque(maxlen = 100), then
+// return the value whose timestamp is closest to t - 30 s (min() keeps the first of equal distances).
+// Timestamps never decrease and neither does the target, so the winner never moves backwards: the
+// search resumes from the previous winner (`cursor`, an absolute push index) and walks forward while a
+// later, different timestamp is strictly closer -- the same element a scan of all 100 entries finds
+// (the fp32 differences are exact, so equal distances only occur for equal or mirror-image timestamps).
+struct Line {
+    float *rt, *rv; int64_t N; int pushes, cursor;
+    __device__ __forceinline__ float transport(float t, float tv)
+    {
+        const int slot = pushes % RING;
+        rt[(int64_t)slot * N] = t; rv[(int64_t)slot * N] = tv;
+        ++pushes;
+        const int oldest = max(0, pushes - RING);
+        int c = max(cursor, oldest);
+        const float target = t - 30.0f;
+        float tc = (c == pushes - 1) ? t : rt[(int64_t)(c % RING) * N];
+        float dc = fabsf(tc - target);
+        for (int j = c + 1; j < pushes; ++j) {
+            const float tj = (j == pushes - 1) ? t : rt[(int64_t)(j % RING) * N];
+            if (tj == tc) continue;                     // same timestamp: the earlier entry wins
+            const float dj = fabsf(tj - target);
+            if (!(dj < dc)) break;
+            c = j; tc = tj; dc = dj;
+        }
+        cursor = c;
+        return (c == pushes - 1) ? tv : rv[(int64_t)(c % RING) * N];
+    }
+};
+
+// One BaseSensor.read + type-specific read() of sensor I at time t.
+template <int I>
+__device__ __forceinline__ void read_sensor(SState &s, Line &ln, const float *tap, int64_t N, double t, float fs,
+                                            float &value, int &rstatus, int &rfault)
+{
+    const SensorSpec sp = spec_of(I, fs);
+    value = __builtin_nanf("");
+    // ---------------- BaseSensor.read
+    if (!(20.0f < s.supply && s.supply < 28.0f)) {                               // :549-569 (and stays so)
+        rstatus = ST_POWER_FAULT; rfault = (s.supply < 20.0f) ? FL_POWER_LOW : FL_POWER_HIGH;
+        s.prev_t = s.last_t; s.last_t = t; s.last_value = value; s.hist_n = min(s.hist_n + 1, 2);
+        return;
+    }
+    s.supply = 24.0f + s.rng.normal(1.0f);                                       // :572
+    if (!(t - s.power_on >= (double)sp.warmup)) {                                // :575-588
+        rstatus = ST_WARMING_UP; rfault = FL_NONE;
+        s.prev_t = s.last_t; s.last_t = t; s.last_value = value; s.hist_n = min(s.hist_n + 1, 2);
+        return;
+    }
+    const bool cal_expired = ((t - s.cal_time) / 3600.0 > (double)sp.cal_valid_h);   // :590-593
+    if (cal_expired) s.status = ST_CAL_EXPIRED;
+    const float temp = tap[sp.tap_T * N];
+    float tv;
+    if (sp.kind == K_PH) tv = tap[sp.tap_self * N] + 0.003f * (temp - 25.0f);   // ph_sensor.py:169-180
+    else if (sp.kind == K_CL_AMP || sp.kind == K_CL_DPD) {                       // chlorine_sensor.py:189-227
+        const float ratio = exp10f(7.5f - tap[sp.tap_pH * N]);
+        tv = tap[sp.tap_self * N] * (0.5f + 0.5f * (ratio / (1.0f + ratio)));
+    } else tv = tap[sp.tap_self * N];                                            // flow_sensor.py:98-102, temperature_sensor.py:105-108
+    if (sp.line >= 0) tv = ln.transport((float)t, tv);                           // :598-609
+    const float drift = sp.drift_rate * (float)((t - s.cal_time) / 3600.0) + s.cal_offset;   // :612-616
+    const float noise = s.rng.normal(sp.precision);                              // :619
+    float cur = 0.5f * (tv + noise + drift) + 0.5f * s.current;                  // :622-626 (hysteresis :630 is a no-op)
+    float rate = 0.0f;                                                           // :638-648
+    if (s.hist_n > 0) {
+        const float dtl = (float)(t - s.last_t);
+        if (dtl > 0.0f && isfinite(s.last_value)) rate = (cur - s.last_value) / dtl;
+    }
+    int f = -1;                                                                  // _check_for_faults :377-407
+    if (!(20.0f < s.supply && s.supply < 28.0f)) f = (s.supply < 20.0f) ? FL_POWER_LOW : FL_POWER_HIGH;
+    else {
+        const float span = sp.hi - sp.lo;
+        if (cur < sp.lo - 0.1f * span || cur > sp.hi + 0.1f * span) f = FL_OUT_OF_RANGE;
+        else if (fabsf(rate) > sp.max_rate) f = FL_RATE_FAULT;
+        else if (s.rng.uniform() < 0.0001f) f = (s.rng.uniform() * 2.0f < 1.0f) ? FL_OPEN_CIRCUIT : FL_SHORT_CIRCUIT;
+    }
+    if (f >= 0) {                                                                // :651-663
+        s.fault = f;
+        if (f == FL_OPEN_CIRCUIT || f == FL_SHORT_CIRCUIT) { s.status = ST_FAILED; cur = __builtin_nanf(""); }
+        else if (f == FL_OUT_OF_RANGE) s.status = ST_OUT_OF_RANGE;
+        else if (f == FL_POWER_LOW || f == FL_POWER_HIGH) s.status = ST_POWER_FAULT;
+        else s.status = ST_RATE_FAULT;
+    } else {                                                                     // :664-682
+        s.fault = FL_NONE;
+        if (!isnan(cur)) {
+            const float b = fminf(fmaxf(cur, sp.lo), sp.hi);
+            if (b != cur) s.status = ST_SATURATED; else if (!cal_expired) s.status = ST_NORMAL;
+            cur = b;
+        }
+        if (fabsf(drift) > 0.1f * (sp.hi - sp.lo) && s.status != ST_CAL_EXPIRED) s.status = ST_DRIFT_WARNING;
+    }
+    s.current = cur;
+    const bool have_dt = s.hist_n >= 1;                                          // len(reading_history) >= 2 after the append
+    const double dtp = t - s.last_t;
+    s.prev_t = s.last_t; s.last_t = t; s.last_value = cur; s.hist_n = min(s.hist_n + 1, 2);
+    rstatus = s.status; rfault = s.fault; value = cur;
+    if (!isfinite(cur)) return;
+    // ---------------- type-specific read()
+    float fin;
+    if (sp.kind == K_PH) {                                                       // ph_sensor.py:182-214,236-336
+        // slow0 = membrane_fouling, slow1 = days_since_cleaning, slow2 = reference_contamination
+        if (have_dt) {
+            const double bio = (s.slow0 > 0.05) ? 0.1 * exp(0.05 * ((double)temp - 25.0)) : 0.001;
+            s.slow0 = fmin(1.0, s.slow0 + (bio + 100.0 * 0.00001) * (dtp / 86400.0));
+            s.slow1 += dtp / 86400.0;
+        }
+        const float elec = s.rng.normal(0.002f * (1.0f + 0.1f * fabsf(cur - 7.0f)));
+        const float junc = s.rng.normal(0.005f * (1.0f + (float)s.slow2));
+        const double days = (t - s.cal_time) / 86400.0;
+        const float slope_pct = fmaxf(90.0f, 100.0f - 0.001f * (float)days);     // ph_sensor.py:262-266
+        float slope_err = 0.0f;
+        if (!(4.0f < cur && cur < 7.0f)) slope_err = fminf(fabsf(cur - 4.0f), fabsf(cur - 7.0f)) * (100.0f - slope_pct) / 100.0f;
+        const float foul_off = (float)s.slow0 * 0.2f;
+        const float foul_noise = s.rng.normal((float)s.slow0 * 0.05f);
+        s.slow2 = fmin(0.5, s.slow2 + 0.0001 * (days / 30.0));
+        fin = cur + elec + junc + slope_err + foul_off + foul_noise + (float)s.slow2 * 0.1f;
+    } else if (sp.kind == K_CL_AMP) {                                            // chlorine_sensor.py:310-331,405-449
+        // slow0 = membrane fouling, slow1 = membrane age [d]
+        if (have_dt) { s.slow0 = fmin(1.0, s.slow0 + 0.01 * (dtp / 86400.0)); s.slow1 += dtp / 86400.0; }
+        const float pol = s.rng.normal(0.005f * (1.0f + (float)s.slow1 / 365.0f));
+        const float dif = s.rng.normal(0.003f);
+        fin = cur * (1.0f - 0.8f * (float)s.slow0) + pol + dif;
+    } else if (sp.kind == K_CL_DPD) {                                            // chlorine_sensor.py:274-308,451-484
+        // slow0 = reagent potency, slow1 = light exposure [h], slow2 = reagent age [d]
+        if (have_dt) {
+            s.slow1 += dtp / 3600.0;
+            const double photo = 1.0 + 0.1 * (s.slow1 / 100.0);
+            s.slow0 = fmax(0.0, s.slow0 - 1.0 * photo * 0.01 * (dtp / 86400.0));
+            s.slow2 += dtp / 86400.0;
+        }
+        fin = cur * (float)s.slow0 * 0.95f + s.rng.normal(0.005f);
+    } else if (sp.kind == K_FLOW_MAG) {                                          // flow_sensor.py:138-178,201-219
+        if (have_dt) s.slow0 += 0.001 * (dtp / 86400.0);                         // electrode fouling
+        fin = cur * fmaxf(0.9f, 1.0f - 0.005f * (float)s.slow0) + s.rng.normal(0.001f * fs);
+        if (fin < 0.01f * fs) fin = 0.0f;
+    } else {                                                                     // temperature_sensor.py:149-171,118-128
+        const float R_meas = 100.0f * (1.0f + 0.00385f * cur) + 2.0f * 0.5f;
+        const float power_mW = (1.0e-3f * 1.0e-3f) * R_meas * 1000.0f;
+        const float T_meas = (R_meas / 100.0f - 1.0f) / 0.00385f;
+        fin = T_meas + 0.001f * power_mW + s.rng.normal(0.001f);
+        fin += 0.01f * (cur - AMBIENT_T);
+    }
+    fin = fminf(fmaxf(fin, sp.lo), sp.hi);
+    s.current = fin; s.last_value = fin; value = fin;
+}
+
+__device__ __forceinline__ void emit(const SensorArgs &a, int i, int64_t r, int k, int steps, int hist0,
+                                     float value, int rstatus, int rfault)
+{
+    const int64_t N = a.N;
+    if (k == steps - 1) { a.out_value[(int64_t)i * N + r] = value; a.out_status[(int64_t)i * N + r] = (uint8_t)rstatus; a.out_fault[(int64_t)i * N + r] = (uint8_t)rfault; }
+    if (a.hist_value) {
+        const int pos = hist0 + k;
+        if (pos < a.hist_cap) {
+            const int64_t o = ((int64_t)pos * NSENS + i) * N + r;
+            a.hist_value[o] = value; a.hist_status[o] = (uint8_t)rstatus; a.hist_fault[o] = (uint8_t)rfault;
+        }
+    }
+}
+
+// group of sensors I0 (and I1 >= 0, read after I0 within a step as in read_all_sensors' dict order) on line LINE
+template <int G, int I0, int I1, int LINE>
+__device__ __forceinline__ void run_group(const SensorArgs &a, int64_t r)
+{
     const int64_t N = a.N;
     const int steps = a.tap_count[r];
     if (steps <= 0) return;
     const float fs = a.full_scale[r];
     const double t_first = a.time_end[r] - a.t_enable[r] - (double)(steps - 1) * a.dt;   // time of the first read
-
-    // two delay lines (inlet: sensors 0 and 5, outlet: 1 and 6)
-    int head[2] = {a.ring_head[0 * N + r], a.ring_head[1 * N + r]};
-    int cnt[2] = {a.ring_cnt[0 * N + r], a.ring_cnt[1 * N + r]};
-
-    for (int i = 0; i < NSENS; ++i) {
-        const SensorSpec sp = spec_of(i, fs);
-        float *F = a.fs + ((int64_t)i * NF) * N + r;
-        double *D = a.ds + ((int64_t)i * ND) * N + r;
-        int32_t *I = a.is + ((int64_t)i * NI) * N + r;
-        float current = F[F_CURRENT * N], supply = F[F_SUPPLY * N];
-        const float cal_offset = F[F_CAL_OFFSET * N];
-        float last_value = F[F_LAST_VALUE * N];
-        const double cal_time = D[D_CAL_TIME * N], power_on = D[D_POWER_ON * N];
-        double last_t = D[D_LAST_T * N], prev_t = D[D_PREV_T * N];
-        double slow0 = D[D_SLOW0 * N], slow1 = D[D_SLOW1 * N], slow2 = D[D_SLOW2 * N];
-        int status = I[I_STATUS * N], fault = I[I_FAULT * N], hist_n = I[I_HIST_N * N];
-        Rng rng = {(uint32_t)(a.reactor_base + r), (uint32_t)i, (uint32_t)I[I_DRAWS * N], a.seed_lo, a.seed_hi};
-        float slope_pct = 100.0f;   // recomputed from the calibration age at every read (ph_sensor.py:262-266)
-
-        // NOTE: the reference reads all seven sensors per step; sensors only interact through the delay
-        // lines, and there the order of pushes matters.  Looping sensor-major over the steps of a launch
-        // keeps each sensor's state in registers, so the lines are processed in a second, step-major
-        // pass below for the four sensors that use them.  Sensors without a line are independent.
-        if (sp.line >= 0) {
-            F[F_CURRENT * N] = current;  // (untouched here; handled in the step-major pass)
-            continue;
-        }
-        for (int k = 0; k < steps; ++k) {
-            const double t = t_first + (double)k * a.dt;
-            const float *tap = a.taps + ((int64_t)k * NTAP) * N + r;
-            float value = __builtin_nanf(""); int rstatus, rfault;
-            // ---------------- BaseSensor.read
-            if (!(20.0f < supply && supply < 28.0f)) {                           // :549-569 (and stays so)
-                rstatus = ST_POWER_FAULT; rfault = (supply < 20.0f) ? FL_POWER_LOW : FL_POWER_HIGH;
-                prev_t = last_t; last_t = t; last_value = value; hist_n = min(hist_n + 1, 2);
-            } else {
-                supply = 24.0f + rng.normal(1.0f);                               // :572
-                if (!(t - power_on >= (double)sp.warmup)) {                      // :575-588
-                    rstatus = ST_WARMING_UP; rfault = FL_NONE;
-                    prev_t = last_t; last_t = t; last_value = value; hist_n = min(hist_n + 1, 2);
-                } else {
-                    const bool cal_expired = ((t - cal_time) / 3600.0 > (double)sp.cal_valid_h);  // :590-593
-                    if (cal_expired) status = ST_CAL_EXPIRED;
-                    // true value
-                    float tv;
-                    if (sp.kind == K_CL_AMP || sp.kind == K_CL_DPD) {            // chlorine_sensor.py:189-227
-                        const float ratio = exp10f(7.5f - tap[sp.tap_pH * N]);
-                        tv = tap[sp.tap_self * N] * (0.5f + 0.5f * (ratio / (1.0f + ratio)));
-                    } else {
-                        tv = tap[sp.tap_self * N];                               // flow_sensor.py:98-102
-                    }
-                    const float drift = sp.drift_rate * (float)((t - cal_time) / 3600.0) + cal_offset;  // :612-616
-                    const float noise = rng.normal(sp.precision);                // :619
-                    float cur = 0.5f * (tv + noise + drift) + 0.5f * current;    // :622-626 (hysteresis :630 is a no-op)
-                    float rate = 0.0f;                                           // :638-648
-                    if (hist_n > 0) {
-                        const float dtl = (float)(t - last_t);
-                        if (dtl > 0.0f && isfinite(last_value)) rate = (cur - last_value) / dtl;
-                    }
-                    int f = -1;                                                  // _check_for_faults :377-407
-                    if (!(20.0f < supply && supply < 28.0f)) f = (supply < 20.0f) ? FL_POWER_LOW : FL_POWER_HIGH;
-                    else {
-                        const float span = sp.hi - sp.lo;
-                        if (cur < sp.lo - 0.1f * span || cur > sp.hi + 0.1f * span) f = FL_OUT_OF_RANGE;
-                        else if (fabsf(rate) > sp.max_rate) f = FL_RATE_FAULT;
-                        else if (rng.uniform() < 0.0001f) f = (rng.uniform() * 2.0f < 1.0f) ? FL_OPEN_CIRCUIT : FL_SHORT_CIRCUIT;
-                    }
-                    if (f >= 0) {                                                // :651-663
-                        fault = f;
-                        if (f == FL_OPEN_CIRCUIT || f == FL_SHORT_CIRCUIT) { status = ST_FAILED; cur = __builtin_nanf(""); }
-                        else if (f == FL_OUT_OF_RANGE) status = ST_OUT_OF_RANGE;
-                        else if (f == FL_POWER_LOW || f == FL_POWER_HIGH) status = ST_POWER_FAULT;
-                        else status = ST_RATE_FAULT;
-                    } else {                                                     // :664-682
-                        fault = FL_NONE;
-                        if (!isnan(cur)) {
-                            const float b = fminf(fmaxf(cur, sp.lo), sp.hi);
-                            if (b != cur) status = ST_SATURATED; else if (!cal_expired) status = ST_NORMAL;
-                            cur = b;
-                        }
-                        if (fabsf(drift) > 0.1f * (sp.hi - sp.lo) && status != ST_CAL_EXPIRED) status = ST_DRIFT_WARNING;
-                    }
-                    current = cur;
-                    const bool have_dt = hist_n >= 1;                            // len(reading_history) >= 2 after the append
-                    const double dtp = t - last_t;
-                    prev_t = last_t; last_t = t; last_value = cur; hist_n = min(hist_n + 1, 2);
-                    rstatus = status; rfault = fault; value = cur;
-                    // ---------------- type-specific read()
-                    if (isfinite(cur)) {
-                        float fin;
-                        if (sp.kind == K_CL_AMP) {                               // chlorine_sensor.py:310-331,405-449
-                            if (have_dt) { slow0 = fmin(1.0, slow0 + 0.01 * (dtp / 86400.0)); slow1 += dtp / 86400.0; }
-                            const float pol = rng.normal(0.005f * (1.0f + (float)slow1 / 365.0f));
-                            const float dif = rng.normal(0.003f);
-                            fin = cur * (1.0f - 0.8f * (float)slow0) + pol + dif;
-                        } else if (sp.kind == K_CL_DPD) {                        // chlorine_sensor.py:274-308,451-484
-                            if (have_dt) {
-                                slow1 += dtp / 3600.0;
-                                const double photo = 1.0 + 0.1 * (slow1 / 100.0);
-                                slow0 = fmax(0.0, slow0 - 1.0 * photo * 0.01 * (dtp / 86400.0));
-                                slow2 += dtp / 86400.0;
-                            }
-                            fin = cur * (float)slow0 * 0.95f + rng.normal(0.005f);
-                        } else {                                                 // flow_sensor.py:138-178,201-219
-                            if (have_dt) slow0 += 0.001 * (dtp / 86400.0);
-                            fin = cur * fmaxf(0.9f, 1.0f - 0.005f * (float)slow0) + rng.normal(0.001f * fs);
-                            if (fin < 0.01f * fs) fin = 0.0f;
-                        }
-                        fin = fminf(fmaxf(fin, sp.lo), sp.hi);
-                        current = fin; last_value = fin; value = fin;
-                    }
-                }
-            }
-            if (k == steps - 1) { a.out_value[(int64_t)i * N + r] = value; a.out_status[(int64_t)i * N + r] = (uint8_t)rstatus; a.out_fault[(int64_t)i * N + r] = (uint8_t)rfault; }
-            if (a.hist_value) {
-                const int pos = a.hist_pos[r] + k;
-                if (pos < a.hist_cap) {
-                    const int64_t o = ((int64_t)pos * NSENS + i) * N + r;
-                    a.hist_value[o] = value; a.hist_status[o] = (uint8_t)rstatus; a.hist_fault[o] = (uint8_t)rfault;
-                }
-            }
-        }
-        F[F_CURRENT * N] = current; F[F_SUPPLY * N] = supply; F[F_LAST_VALUE * N] = last_value;
-        D[D_LAST_T * N] = last_t; D[D_PREV_T * N] = prev_t; D[D_SLOW0 * N] = slow0; D[D_SLOW1 * N] = slow1; D[D_SLOW2 * N] = slow2;
-        I[I_STATUS * N] = status; I[I_FAULT * N] = fault; I[I_HIST_N * N] = hist_n; I[I_DRAWS * N] = (int32_t)rng.draws;
-        (void)slope_pct;
+    const int hist0 = a.hist_value ? a.hist_pos[(int64_t)G * N + r] : 0;
+    Line ln = {nullptr, nullptr, N, 0, 0};
+    if (LINE >= 0) {
+        ln.rt = a.ring_t + ((int64_t)LINE * RING) * N + r; ln.rv = a.ring_v + ((int64_t)LINE * RING) * N + r;
+        ln.pushes = a.ring_push[(int64_t)LINE * N + r]; ln.cursor = a.ring_cursor[(int64_t)LINE * N + r];
     }
-
-    // ---------------- step-major pass for the four sensors that sit on (shared) delay lines:
-    // per step: pH_inlet (0), pH_outlet (1), ..., temp_inlet (5), temp_outlet (6) in suite order
-    const int lined[4] = {0, 1, 5, 6};
-    float current[4], supply[4], cal_offset[4], last_value[4];
-    double cal_time[4], power_on[4], last_t[4], prev_t[4], slow0[4], slow1[4], slow2[4];
-    int status[4], fault[4], hist_n[4];
-    Rng rng[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int i = lined[j];
-        const float *F = a.fs + ((int64_t)i * NF) * N + r; const double *D = a.ds + ((int64_t)i * ND) * N + r;
-        const int32_t *I = a.is + ((int64_t)i * NI) * N + r;
-        current[j] = F[F_CURRENT * N]; supply[j] = F[F_SUPPLY * N]; cal_offset[j] = F[F_CAL_OFFSET * N]; last_value[j] = F[F_LAST_VALUE * N];
-        cal_time[j] = D[D_CAL_TIME * N]; power_on[j] = D[D_POWER_ON * N]; last_t[j] = D[D_LAST_T * N]; prev_t[j] = D[D_PREV_T * N];
-        slow0[j] = D[D_SLOW0 * N]; slow1[j] = D[D_SLOW1 * N]; slow2[j] = D[D_SLOW2 * N];
-        status[j] = I[I_STATUS * N]; fault[j] = I[I_FAULT * N]; hist_n[j] = I[I_HIST_N * N];
-        rng[j] = {(uint32_t)(a.reactor_base + r), (uint32_t)i, (uint32_t)I[I_DRAWS * N], a.seed_lo, a.seed_hi};
-    }
+    SState s0 = load_state(a, I0, r);
+    SState s1 = load_state(a, I1 >= 0 ? I1 : I0, r);
     for (int k = 0; k < steps; ++k) {
         const double t = t_first + (double)k * a.dt;
         const float *tap = a.taps + ((int64_t)k * NTAP) * N + r;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int i = lined[j];
-            const SensorSpec sp = spec_of(i, fs);
-            float value = __builtin_nanf(""); int rstatus, rfault;
-            if (!(20.0f < supply[j] && supply[j] < 28.0f)) {
-                rstatus = ST_POWER_FAULT; rfault = (supply[j] < 20.0f) ? FL_POWER_LOW : FL_POWER_HIGH;
-                prev_t[j] = last_t[j]; last_t[j] = t; last_value[j] = value; hist_n[j] = min(hist_n[j] + 1, 2);
-            } else {
-                supply[j] = 24.0f + rng[j].normal(1.0f);
-                if (!(t - power_on[j] >= (double)sp.warmup)) {
-                    rstatus = ST_WARMING_UP; rfault = FL_NONE;
-                    prev_t[j] = last_t[j]; last_t[j] = t; last_value[j] = value; hist_n[j] = min(hist_n[j] + 1, 2);
-                } else {
-                    const bool cal_expired = ((t - cal_time[j]) / 3600.0 > (double)sp.cal_valid_h);
-                    if (cal_expired) status[j] = ST_CAL_EXPIRED;
-                    const float temp = tap[sp.tap_T * N];
-                    float tv = (sp.kind == K_PH) ? tap[sp.tap_self * N] + 0.003f * (temp - 25.0f)    // ph_sensor.py:169-180
-                                                 : tap[sp.tap_self * N];                             // temperature_sensor.py:105-108
-                    {   // SampleLine.transport_sample base_sensor.py:177-216: push, then closest to t - 30 s
-                        const int ln = sp.line;
-                        float *rt = a.ring_t + ((int64_t)ln * RING) * N + r, *rv = a.ring_v + ((int64_t)ln * RING) * N + r;
-                        rt[(int64_t)head[ln] * N] = (float)t; rv[(int64_t)head[ln] * N] = tv;
-                        head[ln] = (head[ln] + 1) % RING; cnt[ln] = min(cnt[ln] + 1, RING);
-                        const float target = (float)t - 30.0f;
-                        int idx = (head[ln] - cnt[ln] + RING) % RING;          // oldest entry
-                        float best = fabsf(rt[(int64_t)idx * N] - target); int besti = idx;
-                        for (int q = 1; q < cnt[ln]; ++q) {                      // deque order, strict '<': first minimum wins
-                            idx = (idx + 1 == RING) ? 0 : idx + 1;
-                            const float dq = fabsf(rt[(int64_t)idx * N] - target);
-                            if (dq < best) { best = dq; besti = idx; }
-                        }
-                        tv = rv[(int64_t)besti * N];
-                    }
-                    const float drift = sp.drift_rate * (float)((t - cal_time[j]) / 3600.0) + cal_offset[j];
-                    const float noise = rng[j].normal(sp.precision);
-                    float cur = 0.5f * (tv + noise + drift) + 0.5f * current[j];
-                    float rate = 0.0f;
-                    if (hist_n[j] > 0) {
-                        const float dtl = (float)(t - last_t[j]);
-                        if (dtl > 0.0f && isfinite(last_value[j])) rate = (cur - last_value[j]) / dtl;
-                    }
-                    int f = -1;
-                    if (!(20.0f < supply[j] && supply[j] < 28.0f)) f = (supply[j] < 20.0f) ? FL_POWER_LOW : FL_POWER_HIGH;
-                    else {
-                        const float span = sp.hi - sp.lo;
-                        if (cur < sp.lo - 0.1f * span || cur > sp.hi + 0.1f * span) f = FL_OUT_OF_RANGE;
-                        else if (fabsf(rate) > sp.max_rate) f = FL_RATE_FAULT;
-                        else if (rng[j].uniform() < 0.0001f) f = (rng[j].uniform() * 2.0f < 1.0f) ? FL_OPEN_CIRCUIT : FL_SHORT_CIRCUIT;
-                    }
-                    if (f >= 0) {
-                        fault[j] = f;
-                        if (f == FL_OPEN_CIRCUIT || f == FL_SHORT_CIRCUIT) { status[j] = ST_FAILED; cur = __builtin_nanf(""); }
-                        else if (f == FL_OUT_OF_RANGE) status[j] = ST_OUT_OF_RANGE;
-                        else if (f == FL_POWER_LOW || f == FL_POWER_HIGH) status[j] = ST_POWER_FAULT;
-                        else status[j] = ST_RATE_FAULT;
-                    } else {
-                        fault[j] = FL_NONE;
-                        if (!isnan(cur)) {
-                            const float b = fminf(fmaxf(cur, sp.lo), sp.hi);
-                            if (b != cur) status[j] = ST_SATURATED; else if (!cal_expired) status[j] = ST_NORMAL;
-                            cur = b;
-                        }
-                        if (fabsf(drift) > 0.1f * (sp.hi - sp.lo) && status[j] != ST_CAL_EXPIRED) status[j] = ST_DRIFT_WARNING;
-                    }
-                    current[j] = cur;
-                    const bool have_dt = hist_n[j] >= 1;
-                    const double dtp = t - last_t[j];
-                    prev_t[j] = last_t[j]; last_t[j] = t; last_value[j] = cur; hist_n[j] = min(hist_n[j] + 1, 2);
-                    rstatus = status[j]; rfault = fault[j]; value = cur;
-                    if (isfinite(cur)) {
-                        float fin;
-                        if (sp.kind == K_PH) {                                   // ph_sensor.py:182-214,236-336
-                            // slow0 = membrane_fouling, slow1 = days_since_cleaning, slow2 = reference_contamination
-                            if (have_dt) {
-                                const double bio = (slow0[j] > 0.05) ? 0.1 * exp(0.05 * ((double)temp - 25.0)) : 0.001;
-                                slow0[j] = fmin(1.0, slow0[j] + (bio + 100.0 * 0.00001) * (dtp / 86400.0));
-                                slow1[j] += dtp / 86400.0;
-                            }
-                            const float elec = rng[j].normal(0.002f * (1.0f + 0.1f * fabsf(cur - 7.0f)));
-                            const float junc = rng[j].normal(0.005f * (1.0f + (float)slow2[j]));
-                            const double days = (t - cal_time[j]) / 86400.0;
-                            const float slope_pct = fmaxf(90.0f, 100.0f - 0.001f * (float)days);
-                            float slope_err = 0.0f;
-                            if (!(4.0f < cur && cur < 7.0f)) slope_err = fminf(fabsf(cur - 4.0f), fabsf(cur - 7.0f)) * (100.0f - slope_pct) / 100.0f;
-                            const float foul_off = (float)slow0[j] * 0.2f;
-                            const float foul_noise = rng[j].normal((float)slow0[j] * 0.05f);
-                            slow2[j] = fmin(0.5, slow2[j] + 0.0001 * (days / 30.0));
-                            fin = cur + elec + junc + slope_err + foul_off + foul_noise + (float)slow2[j] * 0.1f;
-                        } else {                                                 // temperature_sensor.py:149-171,118-128
-                            const float R_meas = 100.0f * (1.0f + 0.00385f * cur) + 2.0f * 0.5f;
-                            const float power_mW = (1.0e-3f * 1.0e-3f) * R_meas * 1000.0f;
-                            const float T_meas = (R_meas / 100.0f - 1.0f) / 0.00385f;
-                            fin = T_meas + 0.001f * power_mW + rng[j].normal(0.001f);
-                            fin += 0.01f * (cur - AMBIENT_T);
-                        }
-                        fin = fminf(fmaxf(fin, sp.lo), sp.hi);
-                        current[j] = fin; last_value[j] = fin; value = fin;
-                    }
-                }
-            }
-            if (k == steps - 1) { a.out_value[(int64_t)i * N + r] = value; a.out_status[(int64_t)i * N + r] = (uint8_t)rstatus; a.out_fault[(int64_t)i * N + r] = (uint8_t)rfault; }
-            if (a.hist_value) {
-                const int pos = a.hist_pos[r] + k;
-                if (pos < a.hist_cap) {
-                    const int64_t o = ((int64_t)pos * NSENS + i) * N + r;
-                    a.hist_value[o] = value; a.hist_status[o] = (uint8_t)rstatus; a.hist_fault[o] = (uint8_t)rfault;
-                }
-            }
+        float value; int rstatus, rfault;
+        read_sensor<I0>(s0, ln, tap, N, t, fs, value, rstatus, rfault);
+        emit(a, I0, r, k, steps, hist0, value, rstatus, rfault);
+        if (I1 >= 0) {
+            read_sensor<(I1 >= 0 ? I1 : I0)>(s1, ln, tap, N, t, fs, value, rstatus, rfault);
+            emit(a, I1, r, k, steps, hist0, value, rstatus, rfault);
         }
     }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int i = lined[j];
-        float *F = a.fs + ((int64_t)i * NF) * N + r; double *D = a.ds + ((int64_t)i * ND) * N + r; int32_t *I = a.is + ((int64_t)i * NI) * N + r;
-        F[F_CURRENT * N] = current[j]; F[F_SUPPLY * N] = supply[j]; F[F_LAST_VALUE * N] = last_value[j];
-        D[D_LAST_T * N] = last_t[j]; D[D_PREV_T * N] = prev_t[j]; D[D_SLOW0 * N] = slow0[j]; D[D_SLOW1 * N] = slow1[j]; D[D_SLOW2 * N] = slow2[j];
-        I[I_STATUS * N] = status[j]; I[I_FAULT * N] = fault[j]; I[I_HIST_N * N] = hist_n[j]; I[I_DRAWS * N] = (int32_t)rng[j].draws;
+    store_state(a, I0, r, s0);
+    if (I1 >= 0) store_state(a, I1, r, s1);
+    if (LINE >= 0) { a.ring_push[(int64_t)LINE * N + r] = ln.pushes; a.ring_cursor[(int64_t)LINE * N + r] = ln.cursor; }
+    if (a.hist_value) a.hist_pos[(int64_t)G * N + r] = hist0 + steps;
+}
+
+__global__ __launch_bounds__(64) void sensor_suite_kernel(const SensorArgs a)
+{
+    const int64_t r = a.r0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= a.r1) return;
+    switch (blockIdx.y) {                                // wave-uniform
+    case 0: run_group<0, 0, 5, 0>(a, r); break;         // pH_inlet, temp_inlet share the inlet line
+    case 1: run_group<1, 1, 6, 1>(a, r); break;         // pH_outlet, temp_outlet share the outlet line
+    case 2: run_group<2, 2, -1, -1>(a, r); break;       // chlorine_inlet (amperometric)
+    case 3: run_group<3, 3, -1, -1>(a, r); break;       // chlorine_outlet (DPD)
+    default: run_group<4, 4, -1, -1>(a, r); break;      // flow_main (magnetic)
     }
-    a.ring_head[0 * N + r] = head[0]; a.ring_head[1 * N + r] = head[1];
-    a.ring_cnt[0 * N + r] = cnt[0]; a.ring_cnt[1 * N + r] = cnt[1];
-    if (a.hist_value) a.hist_pos[r] += steps;
 }
 
 // initialize_sensors (__main__.py:84-118): construct the suite and calibrate every sensor at the
@@ -410,7 +369,7 @@ struct SensorInitArgs {
     int64_t N;
     const double *cfg_flow, *cfg_cl, *cfg_temp; // [N] ReactorConfiguration.flow_rate / initial_chlorine / temperature
     float *fs; double *ds; int32_t *is; float *full_scale;
-    int32_t *ring_head, *ring_cnt;
+    int32_t *ring_push, *ring_cursor;
     float *out_value; uint8_t *out_status, *out_fault;
     int32_t *hist_pos;
 };
@@ -433,8 +392,8 @@ __global__ __launch_bounds__(256) void sensor_init_kernel(const SensorInitArgs a
         I[I_STATUS * N] = ST_NORMAL; I[I_FAULT * N] = FL_NONE; I[I_HIST_N * N] = 0; I[I_DRAWS * N] = 0;
         a.out_value[(int64_t)i * N + r] = __builtin_nanf(""); a.out_status[(int64_t)i * N + r] = ST_NORMAL; a.out_fault[(int64_t)i * N + r] = FL_NONE;
     }
-    a.ring_head[r] = 0; a.ring_head[N + r] = 0; a.ring_cnt[r] = 0; a.ring_cnt[N + r] = 0;
-    if (a.hist_pos) a.hist_pos[r] = 0;
+    a.ring_push[r] = 0; a.ring_push[N + r] = 0; a.ring_cursor[r] = 0; a.ring_cursor[N + r] = 0;
+    if (a.hist_pos) for (int g = 0; g < 5; ++g) a.hist_pos[(int64_t)g * N + r] = 0;
 }
 
 } // namespace wts

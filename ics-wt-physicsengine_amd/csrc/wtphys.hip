@@ -102,12 +102,12 @@ void launch_sensors(wt_ensemble *h, const wt::StepArgs &a, hipStream_t stream)
     s.seed_lo = (uint32_t)(h->sens_seed & 0xffffffffu); s.seed_hi = (uint32_t)(h->sens_seed >> 32);
     s.n_steps = a.n_steps; s.dt = a.dt; s.taps = h->s_taps; s.tap_count = h->s_tap_count; s.time_end = h->s_tap_time; s.t_enable = h->s_t_enable;
     s.fs = h->s_fs; s.ds = h->s_ds; s.is = h->s_is; s.full_scale = h->s_full_scale;
-    s.ring_t = h->s_ring_t; s.ring_v = h->s_ring_v; s.ring_head = h->s_ring_head; s.ring_cnt = h->s_ring_cnt;
+    s.ring_t = h->s_ring_t; s.ring_v = h->s_ring_v; s.ring_push = h->s_ring_head; s.ring_cursor = h->s_ring_cnt;
     s.out_value = h->s_out_value; s.out_status = h->s_out_status; s.out_fault = h->s_out_fault;
     s.hist_value = h->s_hist_value; s.hist_status = h->s_hist_status; s.hist_fault = h->s_hist_fault;
     s.hist_cap = h->s_hist_cap; s.hist_pos = h->s_hist_pos;
     const unsigned grid = (unsigned)((a.r1 - a.r0 + 63) / 64);
-    hipLaunchKernelGGL(wts::sensor_suite_kernel, dim3(grid), dim3(64), 0, stream, s);
+    hipLaunchKernelGGL(wts::sensor_suite_kernel, dim3(grid, wts::NGROUP), dim3(64), 0, stream, s);
 }
 
 void launch_step(wt_ensemble *h, const wt::StepArgs &a, hipStream_t stream)
@@ -398,7 +398,7 @@ int wt_ensemble_sensors_enable(wt_ensemble *h, uint64_t seed, int64_t reactor_ba
         SALLOC(h->s_hist_value, sizeof(float) * (size_t)history_capacity * wts::NSENS * N);
         SALLOC(h->s_hist_status, (size_t)history_capacity * wts::NSENS * N);
         SALLOC(h->s_hist_fault, (size_t)history_capacity * wts::NSENS * N);
-        SALLOC(h->s_hist_pos, sizeof(int32_t) * N);
+        SALLOC(h->s_hist_pos, sizeof(int32_t) * wts::NGROUP * N);
     }
 #undef SALLOC
     hipError_t e = hipMemcpy(cfg, cfg_flow, sizeof(double) * N, hipMemcpyHostToDevice);
@@ -412,7 +412,7 @@ int wt_ensemble_sensors_enable(wt_ensemble *h, uint64_t seed, int64_t reactor_ba
         wts::SensorInitArgs a;
         a.N = h->N; a.cfg_flow = cfg; a.cfg_cl = cfg + N; a.cfg_temp = cfg + 2 * N;
         a.fs = h->s_fs; a.ds = h->s_ds; a.is = h->s_is; a.full_scale = h->s_full_scale;
-        a.ring_head = h->s_ring_head; a.ring_cnt = h->s_ring_cnt;
+        a.ring_push = h->s_ring_head; a.ring_cursor = h->s_ring_cnt;
         a.out_value = h->s_out_value; a.out_status = h->s_out_status; a.out_fault = h->s_out_fault; a.hist_pos = h->s_hist_pos;
         hipLaunchKernelGGL(wts::sensor_init_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, h->stream, a);
         e = hipGetLastError();
