@@ -373,6 +373,70 @@ class ReactorEnsemble:
                                                                 f.ctypes.data_as(u8), n.ctypes.data_as(C.POINTER(C.c_int32))))
         return v, s, f, n
 
+    # -- plant I/O: one virtual Modbus slave per reactor (NEXT-2 / NEXT-3)
+    INPUT_REGISTERS = {"pH_inlet": 0, "pH_middle": 2, "pH_outlet": 4, "chlorine_inlet": 6, "chlorine_outlet": 8, "flow_rate": 10,
+                       "temperature_inlet": 12, "temperature_outlet": 14, "simulation_time": 100, "system_status": 102}
+    HOLDING_REGISTERS = {"acid_flow_rate": 0, "chlorine_flow_rate": 2, "inlet_flow_rate": 4}
+    DISCRETE_INPUTS = {"sensor_fault_pH_inlet": 0, "sensor_fault_pH_outlet": 1, "sensor_fault_chlorine": 2}
+    IR_WORDS, HR_WORDS = 20, 6
+
+    def enable_plant_io(self) -> None:
+        """Keep the reference loop's Modbus data blocks for every reactor on the device: after each launch
+        of :meth:`step` (one PLC scan; ``fused=False`` scans every outer step like ``__main__.main``) the
+        input image is refreshed from the sensor readings (``update_modbus_inputs``) and the holding image
+        is validated into the boundary conditions (``read_modbus_commands`` + ``apply_boundary_conditions``)."""
+        _native.check(_native.lib().wt_ensemble_plc_enable(self._h))
+
+    @staticmethod
+    def encode_float32(values) -> np.ndarray:
+        """``ModbusEncoder.float32_to_registers`` for an array: (..., 2) uint16 = (high word, low word)."""
+        bits = np.ascontiguousarray(values, dtype=np.float64).astype(np.float32).view(np.uint32)
+        return np.stack([(bits >> 16).astype(np.uint16), (bits & 0xFFFF).astype(np.uint16)], axis=-1)
+
+    @staticmethod
+    def decode_float32(words) -> np.ndarray:
+        """``ModbusDecoder.registers_to_float32`` for an array (..., 2) of (high, low) words."""
+        w = np.asarray(words).astype(np.uint32)
+        return ((w[..., 0] << 16) | w[..., 1]).astype(np.uint32).view(np.float32)
+
+    def write_holding(self, words, first_reactor: int = 0) -> None:
+        """Overwrite the holding image (count, 6) uint16 of reactors first_reactor.. (what masters wrote)."""
+        w = np.ascontiguousarray(words, dtype=np.uint16)
+        if w.ndim != 2 or w.shape[1] != self.HR_WORDS:
+            raise ValueError(f"holding image must be (count, {self.HR_WORDS}) uint16")
+        _native.check(_native.lib().wt_ensemble_plc_write_holding(self._h, w.ctypes.data_as(C.POINTER(C.c_uint16)),
+                                                                 int(first_reactor), int(w.shape[0])))
+
+    def write_commands(self, acid_flow_rate, chlorine_flow_rate, inlet_flow_rate, first_reactor: int = 0) -> None:
+        """``slave.write_holding_register`` of the three actuator setpoints for a block of reactors."""
+        cols = [np.atleast_1d(np.asarray(c, dtype=np.float64)) for c in (acid_flow_rate, chlorine_flow_rate, inlet_flow_rate)]
+        cnt = max(c.shape[0] for c in cols)
+        w = np.concatenate([self.encode_float32(np.broadcast_to(c, (cnt,))) for c in cols], axis=1)
+        self.write_holding(w, first_reactor)
+
+    def input_image(self):
+        """(image (N, 20) uint16, update_ok (N,) bool) -- layout in include/wtphys.h."""
+        img = np.empty((self.n_reactors, self.IR_WORDS), dtype=np.uint16); ok = np.empty(self.n_reactors, dtype=np.uint8)
+        _native.check(_native.lib().wt_ensemble_plc_read_inputs(self._h, img.ctypes.data_as(C.POINTER(C.c_uint16)),
+                                                               ok.ctypes.data_as(C.POINTER(C.c_uint8))))
+        return img, ok.astype(bool)
+
+    def input_blocks(self, reactor: int, image: Optional[np.ndarray] = None):
+        """The reference's ``ir_block`` (200 words) and ``di_block`` (100 bits) of one reactor as lists."""
+        img = self.input_image()[0] if image is None else image
+        row = img[reactor]
+        ir = [0] * 200; di = [0] * 100
+        ir[0:16] = [int(x) for x in row[0:16]]; ir[100:103] = [int(x) for x in row[16:19]]
+        for b in range(3):
+            di[b] = (int(row[19]) >> b) & 1
+        return ir, di
+
+    def boundary(self) -> np.ndarray:
+        """Current boundary block (10, N) in BoundaryConditions field order (after the command path)."""
+        out = np.empty((len(params.BOUNDARY_FIELDS), self.n_reactors), dtype=np.float64)
+        _native.check(_native.lib().wt_ensemble_get_boundary(self._h, _native.dptr(out)))
+        return out
+
     def wave_diag(self) -> Optional[np.ndarray]:
         """Per-wavefront diagnostics of the last launch, (n_waves, 8) int64:
         loop trips, Newton trips, shader clocks, 100 MHz wall ticks, factorize / num_jac /

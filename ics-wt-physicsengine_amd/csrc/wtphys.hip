@@ -3,6 +3,7 @@
 // blocks, launches the gfx950 kernels of wt_device.hpp on the handle's stream.
 #include "wt_device.hpp"
 #include "wt_sensors.hpp"
+#include "wt_plc.hpp"
 #include "../../include/wtphys.h"
 
 #include <cmath>
@@ -69,6 +70,9 @@ struct wt_ensemble {
     int32_t *s_is = nullptr, *s_ring_head = nullptr, *s_ring_cnt = nullptr, *s_hist_pos = nullptr, *s_tap_count = nullptr;
     uint8_t *s_out_status = nullptr, *s_out_fault = nullptr, *s_hist_status = nullptr, *s_hist_fault = nullptr;
     float *s_taps = nullptr; int s_taps_steps = 0; int s_hist_cap = 0;
+    // optional plant I/O: Modbus register images per reactor (wt_plc.hpp); one PLC scan per launch
+    bool plc_on = false;
+    uint16_t *p_ir = nullptr, *p_hr = nullptr; double *p_loop_time = nullptr; uint8_t *p_update_ok = nullptr;
     // optional per-launch HIP-event timing (bench.py roofline accounting)
     bool time_launches = false;
     std::vector<hipEvent_t> lt_pool;   // start/stop pairs
@@ -110,9 +114,26 @@ void launch_sensors(wt_ensemble *h, const wt::StepArgs &a, hipStream_t stream)
     hipLaunchKernelGGL(wts::sensor_suite_kernel, dim3(grid, wts::NGROUP), dim3(64), 0, stream, s);
 }
 
+// the rest of one pass of the reference's loop body after reactor.step: read_all_sensors, update_modbus_inputs,
+// read_modbus_commands + apply_boundary_conditions (__main__.py:398-427), for the reactors of this launch
+void launch_io(wt_ensemble *h, const wt::StepArgs &a, hipStream_t stream)
+{
+    if (!h->sensors_on) return;
+    launch_sensors(h, a, stream);
+    if (!h->plc_on) return;
+    const unsigned grid = (unsigned)((a.r1 - a.r0 + 255) / 256);
+    wtp::PackArgs p;
+    p.N = h->N; p.r0 = a.r0; p.r1 = a.r1; p.value = h->s_out_value; p.fault = h->s_out_fault; p.tap_count = h->s_tap_count;
+    p.loop_time = h->p_loop_time; p.dt = a.dt; p.ir = h->p_ir; p.update_ok = h->p_update_ok;
+    hipLaunchKernelGGL(wtp::pack_inputs_kernel, dim3(grid), dim3(256), 0, stream, p);
+    wtp::CommandArgs c;
+    c.N = h->N; c.r0 = a.r0; c.r1 = a.r1; c.hr = h->p_hr; c.bc = h->bc;
+    hipLaunchKernelGGL(wtp::apply_commands_kernel, dim3(grid), dim3(256), 0, stream, c);
+}
+
 void launch_step(wt_ensemble *h, const wt::StepArgs &a, hipStream_t stream)
 {
-    if (!h->time_launches) { launch_step_raw(h, a, stream); if (h->sensors_on) launch_sensors(h, a, stream); return; }
+    if (!h->time_launches) { launch_step_raw(h, a, stream); launch_io(h, a, stream); return; }
     if (h->lt_used + 2 > h->lt_pool.size()) {
         for (int i = 0; i < 2; ++i) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) { launch_step_raw(h, a, stream); return; } h->lt_pool.push_back(e); }
     }
@@ -120,7 +141,7 @@ void launch_step(wt_ensemble *h, const wt::StepArgs &a, hipStream_t stream)
     launch_step_raw(h, a, stream);
     (void)hipEventRecord(h->lt_pool[h->lt_used + 1], stream);
     h->lt_used += 2;
-    if (h->sensors_on) launch_sensors(h, a, stream);
+    launch_io(h, a, stream);
 }
 
 void launch_step_raw(const wt_ensemble *h, const wt::StepArgs &a, hipStream_t stream)
@@ -231,7 +252,7 @@ int wt_ensemble_destroy(wt_ensemble *h)
     }
     void *sp[] = {h->s_fs, h->s_full_scale, h->s_ring_t, h->s_ring_v, h->s_out_value, h->s_hist_value, h->s_ds, h->s_t_enable, h->s_is,
                   h->s_ring_head, h->s_ring_cnt, h->s_hist_pos, h->s_tap_count, h->s_tap_time, h->s_out_status, h->s_out_fault, h->s_hist_status,
-                  h->s_hist_fault, h->s_taps};
+                  h->s_hist_fault, h->s_taps, h->p_ir, h->p_hr, h->p_loop_time, h->p_update_ok};
     for (void *p : sp) if (p) (void)hipFree(p);
     for (hipEvent_t e : h->lt_pool) (void)hipEventDestroy(e);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
@@ -448,6 +469,70 @@ int wt_ensemble_sensors_history(wt_ensemble *h, float *values, uint8_t *status, 
     if (status) HIP_TRY(hipMemcpyAsync(status, h->s_hist_status, cnt, hipMemcpyDeviceToHost, h->stream));
     if (fault) HIP_TRY(hipMemcpyAsync(fault, h->s_hist_fault, cnt, hipMemcpyDeviceToHost, h->stream));
     if (n_filled) HIP_TRY(hipMemcpyAsync(n_filled, h->s_hist_pos, sizeof(int32_t) * h->N, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return WT_OK;
+}
+
+int wt_ensemble_plc_enable(wt_ensemble *h)
+{
+    if (!h) return fail(WT_E_ARG, "NULL handle");
+    if (!h->sensors_on) return fail(WT_E_STATE, "the register image publishes sensor readings: enable the sensor suite first");
+    if (h->plc_on) return fail(WT_E_STATE, "plant I/O already enabled");
+    HIP_TRY(hipSetDevice(h->device));
+    const size_t N = (size_t)h->N;
+    HIP_TRY(hipMalloc((void **)&h->p_ir, sizeof(uint16_t) * wtp::IR_WORDS * N));
+    HIP_TRY(hipMalloc((void **)&h->p_hr, sizeof(uint16_t) * wtp::HR_WORDS * N));
+    HIP_TRY(hipMalloc((void **)&h->p_loop_time, sizeof(double) * N));
+    HIP_TRY(hipMalloc((void **)&h->p_update_ok, N));
+    // ModbusSequentialDataBlock(0, [0] * size): every register starts at 0 (slave.py:134-137); sim_time = 0.0
+    HIP_TRY(hipMemsetAsync(h->p_ir, 0, sizeof(uint16_t) * wtp::IR_WORDS * N, h->stream));
+    HIP_TRY(hipMemsetAsync(h->p_hr, 0, sizeof(uint16_t) * wtp::HR_WORDS * N, h->stream));
+    HIP_TRY(hipMemsetAsync(h->p_loop_time, 0, sizeof(double) * N, h->stream));
+    HIP_TRY(hipMemsetAsync(h->p_update_ok, 1, N, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    h->plc_on = true;
+    return WT_OK;
+}
+
+int wt_ensemble_plc_write_holding(wt_ensemble *h, const uint16_t *words, int64_t first_reactor, int64_t count)
+{
+    if (!h || !words) return fail(WT_E_ARG, "NULL argument");
+    if (!h->plc_on) return fail(WT_E_STATE, "plant I/O not enabled");
+    if (first_reactor < 0 || count < 0 || first_reactor + count > h->N) return fail(WT_E_ARG, "reactor range outside the ensemble");
+    if (count == 0) return WT_OK;
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipMemcpyAsync(h->p_hr + first_reactor * wtp::HR_WORDS, words, sizeof(uint16_t) * wtp::HR_WORDS * (size_t)count,
+                           hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));   // the caller's buffer is free on return
+    return WT_OK;
+}
+
+int wt_ensemble_plc_read_inputs(wt_ensemble *h, uint16_t *words, uint8_t *update_ok)
+{
+    if (!h) return fail(WT_E_ARG, "NULL handle");
+    if (!h->plc_on) return fail(WT_E_STATE, "plant I/O not enabled");
+    HIP_TRY(hipSetDevice(h->device));
+    if (words) HIP_TRY(hipMemcpyAsync(words, h->p_ir, sizeof(uint16_t) * wtp::IR_WORDS * (size_t)h->N, hipMemcpyDeviceToHost, h->stream));
+    if (update_ok) HIP_TRY(hipMemcpyAsync(update_ok, h->p_update_ok, (size_t)h->N, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return WT_OK;
+}
+
+int wt_ensemble_plc_device(wt_ensemble *h, void **input_image, void **holding_image)
+{
+    if (!h) return fail(WT_E_ARG, "NULL handle");
+    if (!h->plc_on) return fail(WT_E_STATE, "plant I/O not enabled");
+    if (input_image) *input_image = h->p_ir;
+    if (holding_image) *holding_image = h->p_hr;
+    return WT_OK;
+}
+
+int wt_ensemble_get_boundary(wt_ensemble *h, double *bc)
+{
+    if (!h || !bc) return fail(WT_E_ARG, "NULL argument");
+    if (!h->have_bc) return fail(WT_E_STATE, "set_boundary must precede get_boundary");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipMemcpyAsync(bc, h->bc, sizeof(double) * WT_NB * (size_t)h->N, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     return WT_OK;
 }

@@ -169,6 +169,33 @@ int wt_ensemble_sensors_get(wt_ensemble *h, float *values, uint8_t *status, uint
 /* recorded reads [history_capacity][WT_N_SENSORS][N] and the number of reads taken per reactor [N] */
 int wt_ensemble_sensors_history(wt_ensemble *h, float *values, uint8_t *status, uint8_t *fault, int32_t *n_filled);
 
+/* ---- plant I/O around the step (SURVEY.md section 8(f) NEXT-2 driver loop, NEXT-3 register image) ----
+ * One virtual Modbus slave per reactor, as the reference's loop body keeps it (__main__.py:398-427):
+ * after every launch of wt_ensemble_step (= one PLC scan; wt_ensemble_set_schedule's chunk_steps, or
+ * fused = 0 for a scan per outer step as in the reference) the device runs, for the reactors of the launch,
+ *   update_modbus_inputs   (__main__.py:166-224; encoder modbus/protocols.py:35-58; map register_map.py:119-244,364-401)
+ *   read_modbus_commands + apply_boundary_conditions (__main__.py:227-271; decoder protocols.py:155-177)
+ * so a command written to the holding image acts from the next scan on.  Needs the sensor suite.
+ * Input image: [N][WT_IR_WORDS] uint16, words 0..15 = input registers 0..15 (pH_inlet 0-1, pH_middle 2-3
+ * (never written), pH_outlet 4-5, chlorine_inlet 6-7, chlorine_outlet 8-9, flow_rate 10-11, temperature_inlet
+ * 12-13, temperature_outlet 14-15), 16-17 = simulation_time (registers 100-101: the loop's sim_time, which
+ * lags ReactorState.time by one dt, __main__.py:413,446), 18 = system_status (register 102),
+ * 19 = discrete inputs 0..2 (sensor_fault_pH_inlet, _pH_outlet, _chlorine) in bits 0..2.  float32 values
+ * occupy (high word, low word).  Holding image: [N][WT_HR_WORDS] uint16 = holding registers 0..5
+ * (acid_flow_rate, chlorine_flow_rate, inlet_flow_rate), all 0 at start like the reference's data block. */
+#define WT_IR_WORDS 20
+#define WT_HR_WORDS 6
+int wt_ensemble_plc_enable(wt_ensemble *h);
+/* what Modbus masters wrote since the last scan, for reactors [first_reactor, first_reactor + count) */
+int wt_ensemble_plc_write_holding(wt_ensemble *h, const uint16_t *words, int64_t first_reactor, int64_t count);
+/* input image [N][WT_IR_WORDS]; update_ok[N] = 0 where the last update raised in the reference
+ * (a value outside +-1e9, modbus/slave.py:146-147: registers written before it are new, the rest stale) */
+int wt_ensemble_plc_read_inputs(wt_ensemble *h, uint16_t *words, uint8_t *update_ok);
+/* device pointers of both images for co-resident servers / controllers (synchronise first) */
+int wt_ensemble_plc_device(wt_ensemble *h, void **input_image, void **holding_image);
+/* current boundary block [WT_NB][N] (after the command path acted on it) */
+int wt_ensemble_get_boundary(wt_ensemble *h, double *bc);
+
 /* Self-test of the kernel's cross-lane primitives (DPP row / wave shifts, segment
  * sums) against ds_bpermute for a given zone count; *mismatches must come back 0. */
 int wt_selftest_shuffles(int device, int n_zones, int *mismatches);
