@@ -86,6 +86,9 @@ def main() -> int:
                     help="reactor ranges / HIP streams per GPU (0 = library default: min(4, wavefronts/64))")
     ap.add_argument("--sensors", action="store_true",
                     help="BASELINE config 5: also run the fused fp32 sensor suite (7 readings per reactor per step)")
+    ap.add_argument("--plant-io", action="store_true",
+                    help="also keep the per-reactor Modbus register images and run the command path once per launch "
+                         "(--chunk 1 = one PLC scan per outer step, as the reference loop); implies --sensors")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-reactors", type=int, default=4096)
     ap.add_argument("--cpu-sample-steps", type=int, default=100)
@@ -117,8 +120,14 @@ def main() -> int:
     cols, bc = wt.make_ensemble(N, start=rank * N)  # every rank owns a distinct slice
     ens = wt.ReactorEnsemble(cols, n_zones=n, device=local_rank)
     ens.set_boundary(bc)
+    if args.plant_io:
+        args.sensors = True
     if args.sensors:
         ens.enable_sensors(seed=0x5EED5EED1234, reactor_base=rank * N)
+    if args.plant_io:
+        ens.enable_plant_io()
+        # the masters' setpoints = the synthetic boundary (as float32 registers), so the physics workload stays the same
+        ens.write_commands(bc[4], bc[6], bc[0])
 
     def barrier():
         ens.synchronize()
@@ -201,7 +210,8 @@ def main() -> int:
             "config": {
                 "workload": f"{N}-reactor x {n}-zone ensemble per GPU, dt=1 s, fp64, "
                             f"{args.chunk} outer step(s) per launch, {n_streams} reactor range(s)/stream(s)"
-                            + (" + fused fp32 sensor suite" if args.sensors else ""),
+                            + (" + fused fp32 sensor suite" if args.sensors else "")
+                            + (" + Modbus register image / command path per launch" if args.plant_io else ""),
                 "reactors_per_gpu": N, "zones": n, "dt_s": 1.0,
                 "sharding": f"instance-parallel x{world}, final RCCL all_gather only",
             },

@@ -1,13 +1,15 @@
 // wt_plc.hpp -- gfx950 device code of the plant I/O layer around the physics step (SURVEY.md
 // section 8(f) NEXT-2 driver loop, NEXT-3 Modbus register image), one virtual PLC slave per reactor.
 //
-//   pack_inputs_kernel     update_modbus_inputs  __main__.py:166-224  (NaN/inf -> 0.0, system_status, fault bits)
+//   pack_inputs            update_modbus_inputs  __main__.py:166-224  (NaN/inf -> 0.0, system_status, fault bits)
 //                          ModbusEncoder.float32_to_registers  modbus/protocols.py:35-58 (high word, low word)
 //                          addresses  modbus/register_map.py:119-244, 364-401
-//   apply_commands_kernel  read_modbus_commands  __main__.py:227-252, validate_flow_rate :57-63,
+//   apply_commands         read_modbus_commands  __main__.py:227-252, validate_flow_rate :57-63,
 //                          apply_boundary_conditions :255-271, ModbusDecoder.registers_to_float32 protocols.py:155-177
 //
-// Both are byte movers over a few dozen bytes per reactor (thread per reactor, bound by HBM/L2).
+// Both are byte movers over a few dozen bytes per reactor; they run as the epilogue of the sensor-suite
+// kernel (wt_sensors.hpp): of the five sensor-group wavefronts of a 64-reactor block, the one that
+// finishes last publishes the block, one reactor per lane.
 // Image layout (array of structures: a Modbus server answers "registers a..b of unit r" from one
 // contiguous 40-byte record):
 //   input image  ir[r][20] uint16: words 0..15 = input registers 0..15, 16..17 = simulation_time
@@ -25,7 +27,7 @@ constexpr int IR_WORDS = 20, HR_WORDS = 6, NSENS = 7;
 __device__ constexpr int SENSOR_REG[NSENS] = {0, 4, 6, 8, 10, 12, 14};
 
 struct PackArgs {
-    int64_t N, r0, r1;
+    int64_t N;
     const float *value;      // [NSENS][N] last readings (NaN = no reading)
     const uint8_t *fault;    // [NSENS][N] SensorFault codes
     const int32_t *tap_count;// [N] outer steps of the launch that just finished (0: nothing to publish)
@@ -37,10 +39,8 @@ struct PackArgs {
 
 __device__ __forceinline__ uint32_t f32_bits_from_double(double x) { return __float_as_uint((float)x); }   // struct.pack('>f'): RN-even
 
-__global__ __launch_bounds__(256) void pack_inputs_kernel(const PackArgs a)
+__device__ __forceinline__ void pack_inputs(const PackArgs &a, int64_t r)
 {
-    const int64_t r = a.r0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= a.r1) return;
     const int steps = a.tap_count[r];
     if (steps <= 0) return;
     // the loop publishes sim_time BEFORE incrementing it (__main__.py:413 vs :446): the image of step k carries (k-1)*dt
@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void pack_inputs_kernel(const PackArgs a)
 }
 
 struct CommandArgs {
-    int64_t N, r0, r1;
+    int64_t N;
     const uint16_t *hr;      // [N][HR_WORDS]
     double *bc;              // [NB][N] boundary block of the ensemble (rows: 0 inlet flow, 4 acid flow, 6 chlorine flow)
 };
@@ -79,10 +79,8 @@ __device__ __forceinline__ double validate_flow_rate(float v, double max_value)
     return fmax(0.0, fmin((double)v, max_value));
 }
 
-__global__ __launch_bounds__(256) void apply_commands_kernel(const CommandArgs a)
+__device__ __forceinline__ void apply_commands(const CommandArgs &a, int64_t r)
 {
-    const int64_t r = a.r0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= a.r1) return;
     const uint16_t *hr = a.hr + r * HR_WORDS;
     const float acid = __uint_as_float(((uint32_t)hr[0] << 16) | hr[1]);
     const float chlorine = __uint_as_float(((uint32_t)hr[2] << 16) | hr[3]);

@@ -28,6 +28,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "wt_plc.hpp"
 
 namespace wts {
 
@@ -69,6 +70,11 @@ struct SensorArgs {
     uint8_t *hist_status, *hist_fault;
     int hist_cap;
     int32_t *hist_pos;     // [NGROUP][N] next history slot (one copy per sensor group, all equal)
+    int32_t *arrive;       // arrival counters of the reactor blocks (zero between launches)
+    int64_t arrive_base;   // first counter of this launch's reactor range
+    int plc_on;            // publish the readings into the Modbus images and run the command path (wt_plc.hpp)
+    wtp::PackArgs pack;
+    wtp::CommandArgs cmd;
 };
 
 // ---------------------------------------------------------------- Philox4x32-10
@@ -350,16 +356,35 @@ __device__ __forceinline__ void run_group(const SensorArgs &a, int64_t r)
     if (a.hist_value) a.hist_pos[(int64_t)G * N + r] = hist0 + steps;
 }
 
+// grid = (blocks of 64 reactors, NGROUP): one wavefront per (reactor block, sensor group).  Single-wavefront
+// workgroups on purpose: the kernel shares the GPU with physics launches of the other reactor ranges, whose
+// wavefronts each own a whole SIMD's registers, and a one-wave workgroup fits into any SIMD that frees up.
 __global__ __launch_bounds__(64) void sensor_suite_kernel(const SensorArgs a)
 {
-    const int64_t r = a.r0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= a.r1) return;
-    switch (blockIdx.y) {                                // wave-uniform
-    case 0: run_group<0, 0, 5, 0>(a, r); break;         // pH_inlet, temp_inlet share the inlet line
-    case 1: run_group<1, 1, 6, 1>(a, r); break;         // pH_outlet, temp_outlet share the outlet line
-    case 2: run_group<2, 2, -1, -1>(a, r); break;       // chlorine_inlet (amperometric)
-    case 3: run_group<3, 3, -1, -1>(a, r); break;       // chlorine_outlet (DPD)
-    default: run_group<4, 4, -1, -1>(a, r); break;      // flow_main (magnetic)
+    const int64_t r = a.r0 + (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (r < a.r1) {
+        switch (blockIdx.y) {                                // wave-uniform
+        case 0: run_group<0, 0, 5, 0>(a, r); break;         // pH_inlet, temp_inlet share the inlet line
+        case 1: run_group<1, 1, 6, 1>(a, r); break;         // pH_outlet, temp_outlet share the outlet line
+        case 2: run_group<2, 2, -1, -1>(a, r); break;       // chlorine_inlet (amperometric)
+        case 3: run_group<3, 3, -1, -1>(a, r); break;       // chlorine_outlet (DPD)
+        default: run_group<4, 4, -1, -1>(a, r); break;      // flow_main (magnetic)
+        }
+    }
+    if (!a.plc_on) return;
+    // The wavefront that finishes a reactor block last publishes it: update_modbus_inputs, then
+    // read_modbus_commands + apply_boundary_conditions (__main__.py:411-421).  Release our readings,
+    // count arrivals, and let the last arriver acquire everyone else's before it reads them.
+    __threadfence();
+    int prev = 0;
+    if (threadIdx.x == 0) prev = atomicAdd(a.arrive + a.arrive_base + blockIdx.x, 1);
+    prev = __builtin_amdgcn_readfirstlane(prev);
+    if (prev != NGROUP - 1) return;
+    __threadfence();
+    if (threadIdx.x == 0) a.arrive[a.arrive_base + blockIdx.x] = 0;   // ready for the next launch (stream order)
+    if (r < a.r1) {
+        wtp::pack_inputs(a.pack, r);
+        wtp::apply_commands(a.cmd, r);
     }
 }
 

@@ -3,7 +3,6 @@
 // blocks, launches the gfx950 kernels of wt_device.hpp on the handle's stream.
 #include "wt_device.hpp"
 #include "wt_sensors.hpp"
-#include "wt_plc.hpp"
 #include "../../include/wtphys.h"
 
 #include <cmath>
@@ -72,7 +71,7 @@ struct wt_ensemble {
     float *s_taps = nullptr; int s_taps_steps = 0; int s_hist_cap = 0;
     // optional plant I/O: Modbus register images per reactor (wt_plc.hpp); one PLC scan per launch
     bool plc_on = false;
-    uint16_t *p_ir = nullptr, *p_hr = nullptr; double *p_loop_time = nullptr; uint8_t *p_update_ok = nullptr;
+    uint16_t *p_ir = nullptr, *p_hr = nullptr; double *p_loop_time = nullptr; uint8_t *p_update_ok = nullptr; int32_t *p_arrive = nullptr;
     // optional per-launch HIP-event timing (bench.py roofline accounting)
     bool time_launches = false;
     std::vector<hipEvent_t> lt_pool;   // start/stop pairs
@@ -99,8 +98,12 @@ bool row_mode(int n) { return n == 2 || n == 4 || n == 8 || n == 16; }
 
 void launch_step_raw(const wt_ensemble *h, const wt::StepArgs &a, hipStream_t stream);
 
-void launch_sensors(wt_ensemble *h, const wt::StepArgs &a, hipStream_t stream)
+// the rest of one pass of the reference's loop body after reactor.step, for the reactors of this launch:
+// read_all_sensors and -- with plant I/O on -- update_modbus_inputs, read_modbus_commands +
+// apply_boundary_conditions (__main__.py:398-427), one kernel
+void launch_io(wt_ensemble *h, const wt::StepArgs &a, hipStream_t stream, int slot)
 {
+    if (!h->sensors_on) return;
     wts::SensorArgs s;
     s.N = h->N; s.r0 = a.r0; s.r1 = a.r1; s.reactor_base = h->sens_reactor_base;
     s.seed_lo = (uint32_t)(h->sens_seed & 0xffffffffu); s.seed_hi = (uint32_t)(h->sens_seed >> 32);
@@ -110,30 +113,18 @@ void launch_sensors(wt_ensemble *h, const wt::StepArgs &a, hipStream_t stream)
     s.out_value = h->s_out_value; s.out_status = h->s_out_status; s.out_fault = h->s_out_fault;
     s.hist_value = h->s_hist_value; s.hist_status = h->s_hist_status; s.hist_fault = h->s_hist_fault;
     s.hist_cap = h->s_hist_cap; s.hist_pos = h->s_hist_pos;
+    s.plc_on = h->plc_on ? 1 : 0;
+    s.pack.N = h->N; s.pack.value = h->s_out_value; s.pack.fault = h->s_out_fault; s.pack.tap_count = h->s_tap_count;
+    s.pack.loop_time = h->p_loop_time; s.pack.dt = a.dt; s.pack.ir = h->p_ir; s.pack.update_ok = h->p_update_ok;
+    s.cmd.N = h->N; s.cmd.hr = h->p_hr; s.cmd.bc = h->bc;
+    s.arrive = h->p_arrive; s.arrive_base = a.r0 / 64 + slot;   // distinct counters for every block of every range
     const unsigned grid = (unsigned)((a.r1 - a.r0 + 63) / 64);
     hipLaunchKernelGGL(wts::sensor_suite_kernel, dim3(grid, wts::NGROUP), dim3(64), 0, stream, s);
 }
 
-// the rest of one pass of the reference's loop body after reactor.step: read_all_sensors, update_modbus_inputs,
-// read_modbus_commands + apply_boundary_conditions (__main__.py:398-427), for the reactors of this launch
-void launch_io(wt_ensemble *h, const wt::StepArgs &a, hipStream_t stream)
+void launch_step(wt_ensemble *h, const wt::StepArgs &a, hipStream_t stream, int slot)
 {
-    if (!h->sensors_on) return;
-    launch_sensors(h, a, stream);
-    if (!h->plc_on) return;
-    const unsigned grid = (unsigned)((a.r1 - a.r0 + 255) / 256);
-    wtp::PackArgs p;
-    p.N = h->N; p.r0 = a.r0; p.r1 = a.r1; p.value = h->s_out_value; p.fault = h->s_out_fault; p.tap_count = h->s_tap_count;
-    p.loop_time = h->p_loop_time; p.dt = a.dt; p.ir = h->p_ir; p.update_ok = h->p_update_ok;
-    hipLaunchKernelGGL(wtp::pack_inputs_kernel, dim3(grid), dim3(256), 0, stream, p);
-    wtp::CommandArgs c;
-    c.N = h->N; c.r0 = a.r0; c.r1 = a.r1; c.hr = h->p_hr; c.bc = h->bc;
-    hipLaunchKernelGGL(wtp::apply_commands_kernel, dim3(grid), dim3(256), 0, stream, c);
-}
-
-void launch_step(wt_ensemble *h, const wt::StepArgs &a, hipStream_t stream)
-{
-    if (!h->time_launches) { launch_step_raw(h, a, stream); launch_io(h, a, stream); return; }
+    if (!h->time_launches) { launch_step_raw(h, a, stream); launch_io(h, a, stream, slot); return; }
     if (h->lt_used + 2 > h->lt_pool.size()) {
         for (int i = 0; i < 2; ++i) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) { launch_step_raw(h, a, stream); return; } h->lt_pool.push_back(e); }
     }
@@ -141,7 +132,7 @@ void launch_step(wt_ensemble *h, const wt::StepArgs &a, hipStream_t stream)
     launch_step_raw(h, a, stream);
     (void)hipEventRecord(h->lt_pool[h->lt_used + 1], stream);
     h->lt_used += 2;
-    launch_io(h, a, stream);
+    launch_io(h, a, stream, slot);
 }
 
 void launch_step_raw(const wt_ensemble *h, const wt::StepArgs &a, hipStream_t stream)
@@ -252,7 +243,7 @@ int wt_ensemble_destroy(wt_ensemble *h)
     }
     void *sp[] = {h->s_fs, h->s_full_scale, h->s_ring_t, h->s_ring_v, h->s_out_value, h->s_hist_value, h->s_ds, h->s_t_enable, h->s_is,
                   h->s_ring_head, h->s_ring_cnt, h->s_hist_pos, h->s_tap_count, h->s_tap_time, h->s_out_status, h->s_out_fault, h->s_hist_status,
-                  h->s_hist_fault, h->s_taps, h->p_ir, h->p_hr, h->p_loop_time, h->p_update_ok};
+                  h->s_hist_fault, h->s_taps, h->p_ir, h->p_hr, h->p_loop_time, h->p_update_ok, h->p_arrive};
     for (void *p : sp) if (p) (void)hipFree(p);
     for (hipEvent_t e : h->lt_pool) (void)hipEventDestroy(e);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
@@ -331,7 +322,7 @@ int wt_ensemble_step(wt_ensemble *h, double dt, int n_steps, int fused)
     const int S = h->n_sub;
     if (S <= 1) {
         for (int done = 0; done < n_steps; done += chunk) {
-            launch_step(h, make_args(h, dt, (n_steps - done < chunk) ? n_steps - done : chunk), h->stream);
+            launch_step(h, make_args(h, dt, (n_steps - done < chunk) ? n_steps - done : chunk), h->stream, 0);
         }
         HIP_TRY(hipGetLastError());
         return WT_OK;
@@ -351,7 +342,7 @@ int wt_ensemble_step(wt_ensemble *h, double dt, int n_steps, int fused)
         for (int s = 0; s < S; ++s) {
             const int64_t g0 = groups * s / S, g1 = groups * (s + 1) / S;
             a.r0 = g0 * h->R; a.r1 = (g1 * h->R < h->N) ? g1 * h->R : h->N;
-            if (a.r1 > a.r0) launch_step(h, a, h->sub_stream[s]);
+            if (a.r1 > a.r0) launch_step(h, a, h->sub_stream[s], s);
         }
     }
     HIP_TRY(hipGetLastError());
@@ -484,6 +475,9 @@ int wt_ensemble_plc_enable(wt_ensemble *h)
     HIP_TRY(hipMalloc((void **)&h->p_hr, sizeof(uint16_t) * wtp::HR_WORDS * N));
     HIP_TRY(hipMalloc((void **)&h->p_loop_time, sizeof(double) * N));
     HIP_TRY(hipMalloc((void **)&h->p_update_ok, N));
+    const size_t n_arrive = N / 64 + WT_MAX_STREAMS + 2;
+    HIP_TRY(hipMalloc((void **)&h->p_arrive, sizeof(int32_t) * n_arrive));
+    HIP_TRY(hipMemsetAsync(h->p_arrive, 0, sizeof(int32_t) * n_arrive, h->stream));
     // ModbusSequentialDataBlock(0, [0] * size): every register starts at 0 (slave.py:134-137); sim_time = 0.0
     HIP_TRY(hipMemsetAsync(h->p_ir, 0, sizeof(uint16_t) * wtp::IR_WORDS * N, h->stream));
     HIP_TRY(hipMemsetAsync(h->p_hr, 0, sizeof(uint16_t) * wtp::HR_WORDS * N, h->stream));
