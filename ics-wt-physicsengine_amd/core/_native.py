@@ -36,7 +36,7 @@ class SolverStats(C.Structure):
 
 def build(force: bool = False, verbose: bool = False) -> str:
     """Compile csrc/wtphys.hip for gfx950 into csrc/libwtphys.so (hipcc)."""
-    srcs = [os.path.join(CSRC, f) for f in ("wtphys.hip", "wt_device.hpp", "wt_sensors.hpp")]
+    srcs = [os.path.join(CSRC, f) for f in ("wtphys.hip", "wt_device.hpp", "wt_sensors.hpp", "wt_plc.hpp", "wt_diag.hpp")]
     srcs.append(os.path.join(os.path.dirname(_PKG), "include", "wtphys.h"))
     stale = (not os.path.exists(LIB_PATH)
              or os.path.getmtime(LIB_PATH) < max(os.path.getmtime(s) for s in srcs))
@@ -99,6 +99,7 @@ def lib():
     L.wt_ensemble_plc_read_inputs.argtypes = [vp, u16p, u8p]
     L.wt_ensemble_plc_device.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
     L.wt_ensemble_get_boundary.argtypes = [vp, dp]
+    L.wt_ensemble_diagnostics.argtypes = [vp, dp]
     L.wt_ensemble_wave_diag.argtypes = [vp, C.POINTER(C.c_int64), C.c_int64, C.POINTER(C.c_int64)]
     L.wt_ensemble_size.argtypes = [vp]
     L.wt_ensemble_size.restype = C.c_int64
@@ -109,7 +110,7 @@ def lib():
                  "wt_ensemble_get_state", "wt_ensemble_get_derived", "wt_ensemble_get_status",
                  "wt_ensemble_clear_status", "wt_ensemble_get_stats", "wt_ensemble_rhs",
                  "wt_ensemble_export_state_device", "wt_ensemble_set_stream", "wt_ensemble_timer_start",
-                 "wt_ensemble_plc_enable", "wt_ensemble_plc_write_holding", "wt_ensemble_plc_read_inputs", "wt_ensemble_plc_device", "wt_ensemble_get_boundary",
+                 "wt_ensemble_diagnostics", "wt_ensemble_plc_enable", "wt_ensemble_plc_write_holding", "wt_ensemble_plc_read_inputs", "wt_ensemble_plc_device", "wt_ensemble_get_boundary",
                  "wt_ensemble_timer_stop", "wt_ensemble_zones", "wt_ph_solve", "wt_selftest_shuffles", "wt_ensemble_wave_diag", "wt_ensemble_set_schedule", "wt_ensemble_set_sync", "wt_ensemble_set_step_limit", "wt_ensemble_sensors_enable", "wt_ensemble_sensors_get",
                  "wt_ensemble_sensors_history", "wt_ensemble_launch_timing", "wt_ensemble_launch_stats"):
         getattr(L, name).restype = C.c_int

@@ -437,6 +437,20 @@ class ReactorEnsemble:
         _native.check(_native.lib().wt_ensemble_get_boundary(self._h, _native.dptr(out)))
         return out
 
+    # -- diagnostics (NEXT-4)
+    DIAGNOSTIC_FIELDS = ("total_chlorine_mg", "total_H_mol", "total_OH_mol", "charge_balance_mol", "thermal_energy_kJ",
+                         "pH_CV", "pH_segregation", "chlorine_CV", "chlorine_segregation", "thermocline_depth_m") + tuple(
+        f"{p}_{k}" for p in ("pH", "chlorine", "temperature")
+        for k in ("mean_value", "std_value", "max_value", "min_value", "range", "max_gradient", "mean_gradient", "gradient_location"))
+
+    def diagnostics(self, as_dict: bool = True):
+        """``validate_conservation`` + ``calculate_mixing_quality`` (pH, chlorine) + ``identify_thermocline``
+        (NaN = None) + ``calculate_spatial_gradients`` (pH, chlorine, temperature) of every reactor,
+        reduced on the device: dict name -> (N,) array, or the raw (34, N) block."""
+        out = np.empty((len(self.DIAGNOSTIC_FIELDS), self.n_reactors), dtype=np.float64)
+        _native.check(_native.lib().wt_ensemble_diagnostics(self._h, _native.dptr(out)))
+        return dict(zip(self.DIAGNOSTIC_FIELDS, out)) if as_dict else out
+
     def wave_diag(self) -> Optional[np.ndarray]:
         """Per-wavefront diagnostics of the last launch, (n_waves, 8) int64:
         loop trips, Newton trips, shader clocks, 100 MHz wall ticks, factorize / num_jac /

@@ -3,6 +3,7 @@
 // blocks, launches the gfx950 kernels of wt_device.hpp on the handle's stream.
 #include "wt_device.hpp"
 #include "wt_sensors.hpp"
+#include "wt_diag.hpp"
 #include "../../include/wtphys.h"
 
 #include <cmath>
@@ -71,6 +72,7 @@ struct wt_ensemble {
     float *s_taps = nullptr; int s_taps_steps = 0; int s_hist_cap = 0;
     // optional plant I/O: Modbus register images per reactor (wt_plc.hpp); one PLC scan per launch
     bool plc_on = false;
+    double *diag_out = nullptr;
     uint16_t *p_ir = nullptr, *p_hr = nullptr; double *p_loop_time = nullptr; uint8_t *p_update_ok = nullptr; int32_t *p_arrive = nullptr;
     // optional per-launch HIP-event timing (bench.py roofline accounting)
     bool time_launches = false;
@@ -243,7 +245,7 @@ int wt_ensemble_destroy(wt_ensemble *h)
     }
     void *sp[] = {h->s_fs, h->s_full_scale, h->s_ring_t, h->s_ring_v, h->s_out_value, h->s_hist_value, h->s_ds, h->s_t_enable, h->s_is,
                   h->s_ring_head, h->s_ring_cnt, h->s_hist_pos, h->s_tap_count, h->s_tap_time, h->s_out_status, h->s_out_fault, h->s_hist_status,
-                  h->s_hist_fault, h->s_taps, h->p_ir, h->p_hr, h->p_loop_time, h->p_update_ok, h->p_arrive};
+                  h->s_hist_fault, h->s_taps, h->p_ir, h->p_hr, h->p_loop_time, h->p_update_ok, h->p_arrive, h->diag_out};
     for (void *p : sp) if (p) (void)hipFree(p);
     for (hipEvent_t e : h->lt_pool) (void)hipEventDestroy(e);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
@@ -527,6 +529,22 @@ int wt_ensemble_get_boundary(wt_ensemble *h, double *bc)
     if (!h->have_bc) return fail(WT_E_STATE, "set_boundary must precede get_boundary");
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipMemcpyAsync(bc, h->bc, sizeof(double) * WT_NB * (size_t)h->N, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return WT_OK;
+}
+
+int wt_ensemble_diagnostics(wt_ensemble *h, double *out)
+{
+    if (!h || !out) return fail(WT_E_ARG, "NULL argument");
+    if (!h->have_state) return fail(WT_E_STATE, "set_state must precede diagnostics");
+    HIP_TRY(hipSetDevice(h->device));
+    const size_t bytes = sizeof(double) * wtd::N_DIAG * (size_t)h->N;
+    if (!h->diag_out) HIP_TRY(hipMalloc((void **)&h->diag_out, bytes));
+    wtd::DiagArgs a;
+    a.N = h->N; a.n = h->n; a.par = h->par; a.pH = h->pH; a.Cl = h->Cl; a.T = h->T; a.H = h->dH; a.out = h->diag_out;
+    hipLaunchKernelGGL(wtd::diagnostics_kernel, dim3((unsigned)((h->N + 63) / 64)), dim3(64), 0, h->stream, a);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out, h->diag_out, bytes, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     return WT_OK;
 }

@@ -196,6 +196,21 @@ int wt_ensemble_plc_device(wt_ensemble *h, void **input_image, void **holding_im
 /* current boundary block [WT_NB][N] (after the command path acted on it) */
 int wt_ensemble_get_boundary(wt_ensemble *h, double *bc);
 
+/* ---- reactor diagnostics (SURVEY.md section 8(f) NEXT-4): reductions over the zones of every reactor ----
+ * out: host [WT_N_DIAG][N] doubles, rows
+ *   0 total_chlorine_mg, 1 total_H_mol, 2 total_OH_mol, 3 charge_balance_mol, 4 thermal_energy_kJ
+ *                                   IntegratedCSTR.validate_conservation (reactor.py:570-611)
+ *   5 pH CV, 6 pH segregation index, 7 chlorine CV, 8 chlorine segregation index
+ *                                   TransportModel.calculate_mixing_quality (transport.py:338-384, reactor.py:638-639)
+ *   9 thermocline depth from the top [m], NaN where the reference returns None
+ *                                   SpatialModel.identify_thermocline (spatial.py:352-379)
+ *   10 + 8 p + {0 mean_value, 1 std_value, 2 max_value, 3 min_value, 4 range, 5 max_gradient, 6 mean_gradient,
+ *   7 gradient_location}, p = 0 pH, 1 chlorine, 2 temperature
+ *                                   SpatialModel.calculate_spatial_gradients (spatial.py:440-477)
+ * evaluated on the current state (the derived H+ of the last step; call after wt_ensemble_step). */
+#define WT_N_DIAG 34
+int wt_ensemble_diagnostics(wt_ensemble *h, double *out);
+
 /* Self-test of the kernel's cross-lane primitives (DPP row / wave shifts, segment
  * sums) against ds_bpermute for a given zone count; *mismatches must come back 0. */
 int wt_selftest_shuffles(int device, int n_zones, int *mismatches);
