@@ -375,22 +375,6 @@ struct cplx { double r, i; };
 __device__ __forceinline__ cplx cmul(cplx a, cplx b) { return {a.r * b.r - a.i * b.i, a.r * b.i + a.i * b.r}; }
 __device__ __forceinline__ cplx cinv(cplx a) { const double q = rcp(a.r * a.r + a.i * a.i); return {a.r * q, -a.i * q}; }
 
-template <bool ROW, int LV, int l>
-__device__ __forceinline__ void pcr_solve_real_level(const Lane &L, const FStore<LV> &F, int s0, double &b)
-{
-    constexpr int s = 1 << l;
-    const bool vlo = L.z - s >= 0, vhi = L.z + s < L.n;
-    const double b_lo = from_lo<ROW, s>(b), b_hi = from_hi<ROW, s>(b);
-    b = b - F.ld(s0 + 2 * l) * keep_if(vlo, b_lo) - F.ld(s0 + 2 * l + 1) * keep_if(vhi, b_hi);
-    if constexpr (l + 1 < LV) pcr_solve_real_level<ROW, LV, l + 1>(L, F, s0, b);
-}
-template <bool ROW, int LV>
-__device__ __forceinline__ double pcr_solve_real(const Lane &L, const FStore<LV> &F, int s0, double b)
-{
-    pcr_solve_real_level<ROW, LV, 0>(L, F, s0, b);
-    return b * F.ld(s0 + 2 * LV);
-}
-
 template <bool ROW, int S> __device__ __forceinline__ cplx cfrom_lo(cplx a) { return {from_lo<ROW, S>(a.r), from_lo<ROW, S>(a.i)}; }
 template <bool ROW, int S> __device__ __forceinline__ cplx cfrom_hi(cplx a) { return {from_hi<ROW, S>(a.r), from_hi<ROW, S>(a.i)}; }
 
@@ -465,18 +449,43 @@ __device__ __forceinline__ void factorize(const Lane &L, const Jac &J, double h,
     }
 }
 
-// x = (mu_real/h I - J)^-1 b, in place, b indexed by species
+// x = (mu_real/h I - J)^-1 b, in place, b indexed by species.  The factors of all three systems are
+// fetched from LDS in one batch up front (one exposed LDS round trip instead of one per level).
+template <int LV> struct RealFactors { double a[LV], g[LV], inv; };
+
+template <bool ROW, int LV, int l>
+__device__ __forceinline__ void pcr_real_level(const Lane &L, const RealFactors<LV> &s, double &b)
+{
+    constexpr int st = 1 << l;
+    const bool vlo = L.z - st >= 0, vhi = L.z + st < L.n;
+    const double b_lo = from_lo<ROW, st>(b), b_hi = from_hi<ROW, st>(b);
+    b = b - s.a[l] * keep_if(vlo, b_lo) - s.g[l] * keep_if(vhi, b_hi);
+    if constexpr (l + 1 < LV) pcr_real_level<ROW, LV, l + 1>(L, s, b);
+}
+
 template <bool ROW, int LV>
 __device__ __forceinline__ void solve_real(const Lane &L, const Jac &J, const FStore<LV> &F, double b[3])
 {
     using S = FSlots<LV>;
-    const double xT = pcr_solve_real<ROW, LV>(L, F, 0 * S::RS, b[STT]);
+    RealFactors<LV> fT, fP, fC;
+#pragma unroll
+    for (int l = 0; l < LV; ++l) {
+        fT.a[l] = F.ld(0 * S::RS + 2 * l); fT.g[l] = F.ld(0 * S::RS + 2 * l + 1);
+        fP.a[l] = F.ld(1 * S::RS + 2 * l); fP.g[l] = F.ld(1 * S::RS + 2 * l + 1);
+        fC.a[l] = F.ld(2 * S::RS + 2 * l); fC.g[l] = F.ld(2 * S::RS + 2 * l + 1);
+    }
+    fT.inv = F.ld(0 * S::RS + 2 * LV); fP.inv = F.ld(1 * S::RS + 2 * LV); fC.inv = F.ld(2 * S::RS + 2 * LV);
+    double xT = b[STT];
+    pcr_real_level<ROW, LV, 0>(L, fT, xT);
+    xT *= fT.inv;
     const double xT_lo_r = from_lo<ROW, 1>(xT), xT_hi_r = from_hi<ROW, 1>(xT);
     const double xT_lo = keep_if(L.has_lo, xT_lo_r), xT_hi = keep_if(L.has_hi, xT_hi_r); // J.pt/ct[0,2] are 0 there
-    const double bp = b[SPH] + (J.pt[0] * xT_lo + J.pt[1] * xT + J.pt[2] * xT_hi);
-    const double xP = pcr_solve_real<ROW, LV>(L, F, 1 * S::RS, bp);
-    const double bc = b[SCL] + (J.ct[0] * xT_lo + J.ct[1] * xT + J.ct[2] * xT_hi) + J.cp * xP;
-    const double xC = pcr_solve_real<ROW, LV>(L, F, 2 * S::RS, bc);
+    double xP = b[SPH] + (J.pt[0] * xT_lo + J.pt[1] * xT + J.pt[2] * xT_hi);
+    pcr_real_level<ROW, LV, 0>(L, fP, xP);
+    xP *= fP.inv;
+    double xC = b[SCL] + (J.ct[0] * xT_lo + J.ct[1] * xT + J.ct[2] * xT_hi) + J.cp * xP;
+    pcr_real_level<ROW, LV, 0>(L, fC, xC);
+    xC *= fC.inv;
     b[SPH] = xP; b[SCL] = xC; b[STT] = xT;
 }
 
