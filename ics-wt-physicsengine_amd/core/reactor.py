@@ -408,9 +408,12 @@ class ReactorEnsemble:
                                                                  int(first_reactor), int(w.shape[0])))
 
     def write_commands(self, acid_flow_rate, chlorine_flow_rate, inlet_flow_rate, first_reactor: int = 0) -> None:
-        """``slave.write_holding_register`` of the three actuator setpoints for a block of reactors."""
-        cols = [np.atleast_1d(np.asarray(c, dtype=np.float64)) for c in (acid_flow_rate, chlorine_flow_rate, inlet_flow_rate)]
-        cnt = max(c.shape[0] for c in cols)
+        """``slave.write_holding_register`` of the three actuator setpoints for a block of reactors
+        (arrays: one entry per reactor starting at ``first_reactor``; all scalars: every reactor from there on)."""
+        raw = [np.asarray(c, dtype=np.float64) for c in (acid_flow_rate, chlorine_flow_rate, inlet_flow_rate)]
+        cols = [np.atleast_1d(c) for c in raw]
+        # scalars only: the same setpoints for every reactor from first_reactor on
+        cnt = (self.n_reactors - int(first_reactor)) if all(c.ndim == 0 for c in raw) else max(c.shape[0] for c in cols)
         w = np.concatenate([self.encode_float32(np.broadcast_to(c, (cnt,))) for c in cols], axis=1)
         self.write_holding(w, first_reactor)
 
