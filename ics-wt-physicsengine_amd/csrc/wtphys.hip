@@ -96,6 +96,24 @@ wt::StepArgs make_args(const wt_ensemble *h, double dt, int n_steps)
     return a;
 }
 
+template <class T> void free_and_null(T *&p) { if (p) (void)hipFree(p); p = nullptr; }
+
+void release_sensor_buffers(wt_ensemble *h)
+{
+    free_and_null(h->s_fs); free_and_null(h->s_full_scale); free_and_null(h->s_ring_t); free_and_null(h->s_ring_v);
+    free_and_null(h->s_out_value); free_and_null(h->s_hist_value); free_and_null(h->s_ds); free_and_null(h->s_t_enable);
+    free_and_null(h->s_is); free_and_null(h->s_ring_head); free_and_null(h->s_ring_cnt); free_and_null(h->s_hist_pos);
+    free_and_null(h->s_tap_count); free_and_null(h->s_tap_time); free_and_null(h->s_out_status); free_and_null(h->s_out_fault);
+    free_and_null(h->s_hist_status); free_and_null(h->s_hist_fault); free_and_null(h->s_taps);
+    h->s_taps_steps = 0; h->s_hist_cap = 0; h->sensors_on = false;
+}
+
+void release_plc_buffers(wt_ensemble *h)
+{
+    free_and_null(h->p_ir); free_and_null(h->p_hr); free_and_null(h->p_loop_time); free_and_null(h->p_update_ok); free_and_null(h->p_arrive);
+    h->plc_on = false;
+}
+
 bool row_mode(int n) { return n == 2 || n == 4 || n == 8 || n == 16; }
 
 void launch_step_raw(const wt_ensemble *h, const wt::StepArgs &a, hipStream_t stream);
@@ -392,7 +410,7 @@ int wt_ensemble_sensors_enable(wt_ensemble *h, uint64_t seed, int64_t reactor_ba
     const size_t N = (size_t)h->N;
     double *cfg = nullptr;
     HIP_TRY(hipMalloc((void **)&cfg, sizeof(double) * 3 * N));
-#define SALLOC(ptr, bytes) do { if (hipMalloc((void **)&(ptr), (bytes)) != hipSuccess) { (void)hipFree(cfg); return fail(WT_E_HIP, "hipMalloc (sensors) failed"); } } while (0)
+#define SALLOC(ptr, bytes) do { if (hipMalloc((void **)&(ptr), (bytes)) != hipSuccess) { (void)hipFree(cfg); release_sensor_buffers(h); return fail(WT_E_HIP, "hipMalloc (sensors) failed"); } } while (0)
     SALLOC(h->s_fs, sizeof(float) * wts::NSENS * wts::NF * N);
     SALLOC(h->s_ds, sizeof(double) * wts::NSENS * wts::ND * N);
     SALLOC(h->s_is, sizeof(int32_t) * wts::NSENS * wts::NI * N);
@@ -433,7 +451,7 @@ int wt_ensemble_sensors_enable(wt_ensemble *h, uint64_t seed, int64_t reactor_ba
     }
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     (void)hipFree(cfg);
-    if (e != hipSuccess) return fail(WT_E_HIP, std::string("sensors_enable: ") + hipGetErrorString(e));
+    if (e != hipSuccess) { release_sensor_buffers(h); return fail(WT_E_HIP, std::string("sensors_enable: ") + hipGetErrorString(e)); }
     h->sens_seed = seed; h->sens_reactor_base = reactor_base;
     h->sensors_on = true;
     return WT_OK;
@@ -473,19 +491,20 @@ int wt_ensemble_plc_enable(wt_ensemble *h)
     if (h->plc_on) return fail(WT_E_STATE, "plant I/O already enabled");
     HIP_TRY(hipSetDevice(h->device));
     const size_t N = (size_t)h->N;
-    HIP_TRY(hipMalloc((void **)&h->p_ir, sizeof(uint16_t) * wtp::IR_WORDS * N));
-    HIP_TRY(hipMalloc((void **)&h->p_hr, sizeof(uint16_t) * wtp::HR_WORDS * N));
-    HIP_TRY(hipMalloc((void **)&h->p_loop_time, sizeof(double) * N));
-    HIP_TRY(hipMalloc((void **)&h->p_update_ok, N));
     const size_t n_arrive = N / 64 + WT_MAX_STREAMS + 2;
-    HIP_TRY(hipMalloc((void **)&h->p_arrive, sizeof(int32_t) * n_arrive));
-    HIP_TRY(hipMemsetAsync(h->p_arrive, 0, sizeof(int32_t) * n_arrive, h->stream));
+    hipError_t e = hipMalloc((void **)&h->p_ir, sizeof(uint16_t) * wtp::IR_WORDS * N);
+    if (e == hipSuccess) e = hipMalloc((void **)&h->p_hr, sizeof(uint16_t) * wtp::HR_WORDS * N);
+    if (e == hipSuccess) e = hipMalloc((void **)&h->p_loop_time, sizeof(double) * N);
+    if (e == hipSuccess) e = hipMalloc((void **)&h->p_update_ok, N);
+    if (e == hipSuccess) e = hipMalloc((void **)&h->p_arrive, sizeof(int32_t) * n_arrive);
     // ModbusSequentialDataBlock(0, [0] * size): every register starts at 0 (slave.py:134-137); sim_time = 0.0
-    HIP_TRY(hipMemsetAsync(h->p_ir, 0, sizeof(uint16_t) * wtp::IR_WORDS * N, h->stream));
-    HIP_TRY(hipMemsetAsync(h->p_hr, 0, sizeof(uint16_t) * wtp::HR_WORDS * N, h->stream));
-    HIP_TRY(hipMemsetAsync(h->p_loop_time, 0, sizeof(double) * N, h->stream));
-    HIP_TRY(hipMemsetAsync(h->p_update_ok, 1, N, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (e == hipSuccess) e = hipMemsetAsync(h->p_ir, 0, sizeof(uint16_t) * wtp::IR_WORDS * N, h->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(h->p_hr, 0, sizeof(uint16_t) * wtp::HR_WORDS * N, h->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(h->p_loop_time, 0, sizeof(double) * N, h->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(h->p_update_ok, 1, N, h->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(h->p_arrive, 0, sizeof(int32_t) * n_arrive, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e != hipSuccess) { release_plc_buffers(h); return fail(WT_E_HIP, std::string("plc_enable: ") + hipGetErrorString(e)); }
     h->plc_on = true;
     return WT_OK;
 }
