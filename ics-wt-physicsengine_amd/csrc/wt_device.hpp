@@ -745,6 +745,17 @@ __device__ __forceinline__ double predict_factor(double h_abs, bool have_old, do
 }
 
 // ---------------------------------------------------------------- the solver state machine
+// The per-reactor yes/no state of the solver lives in the bits of ONE VGPR (`fl` in step_kernel).  As separate
+// `bool`s every one of them is a 64-bit lane mask in an SGPR pair for the whole loop -- two dozen of them exhaust
+// the scalar register file and the compiler spills SGPRs through v_writelane / v_readlane.
+struct Flag {
+    uint32_t &w; const uint32_t m;
+    __device__ __forceinline__ operator bool() const { return (w & m) != 0u; }
+    __device__ __forceinline__ Flag &operator=(bool v) { w = v ? (w | m) : (w & ~m); return *this; }
+    __device__ __forceinline__ Flag &operator=(const Flag &o) { return *this = (bool)o; }
+    __device__ __forceinline__ Flag &operator|=(bool v) { w = v ? (w | m) : w; return *this; }
+};
+
 enum Phase : int {
     PH_OUTER_BEGIN = 0, // start an outer step: next trip evaluates f0 = f(y0)            radau.py:303
     PH_F1,              // trip evaluated f0; next evaluates f(y0 + h0 f0)                  common.py:120-122
@@ -792,25 +803,26 @@ __global__ __launch_bounds__(64) void step_kernel(const StepArgs a)
     __shared__ double lds_factors[FSlots<LV>::LDS_SLOTS * 64];
     FStore<LV> F;
     F.base = lds_factors + (threadIdx.x & 63);
-    double fac[3] = {0, 0, 0}; bool have_fac = false;
+    uint32_t fl = 1u << 4;                            // current_jac = true
+    Flag have_fac{fl, 1u << 0}, have_old{fl, 1u << 1}, have_old_l{fl, 1u << 2}, have_sol{fl, 1u << 3}, current_jac{fl, 1u << 4},
+         have_lu{fl, 1u << 5}, rejected{fl, 1u << 6}, keep_h{fl, 1u << 7}, have_norm_old{fl, 1u << 8}, have_rate{fl, 1u << 9},
+         bad{fl, 1u << 10}, failed{fl, 1u << 11}, f_valid{fl, 1u << 12}, need_jac{fl, 1u << 13}, wrote_k{fl, 1u << 14},
+         advanced{fl, 1u << 15}, limit_hit{fl, 1u << 16}, pend_f{fl, 1u << 17}, jac_after_fnew{fl, 1u << 18};
+    double fac[3] = {0, 0, 0};
     double t_out = a.time[r];                         // ReactorState.time
     double t = 0, t_bound = 0, max_step = 0;
     double h = 0, t_new = 0, h_abs = 0, h_abs_l = 0, min_step = 0;
     double h_abs_old = 0, err_old = 0, h_abs_old_l = 0, err_old_l = 0;
-    bool have_old = false, have_old_l = false;
-    double sol_t_old = 0, sol_h = 1; bool have_sol = false;
-    bool current_jac = true, have_lu = false, rejected = false, keep_h = false;
-    int kk = 0, n_iter = 0; double dW_norm_old = 0, rate = 0; bool have_norm_old = false, have_rate = false;
+    double sol_t_old = 0, sol_h = 1;
+    int kk = 0, n_iter = 0; double dW_norm_old = 0, rate = 0;
     double error_norm = 0, safety = 0;
     double d0 = 0, d1 = 0, h0 = 0;                    // select_initial_step
-    bool bad = false, failed = false, f_valid = false;
-    bool need_jac = false;
-    double dH = 0, dR = 0, dK = 0; bool wrote_k = false, advanced = false;
+    double dH = 0, dR = 0, dK = 0;
     SolverCounters cnt = {0, 0, 0, 0, 0};
     int steps_left = a.n_steps;
-    int attempts = 0; bool limit_hit = false;   // guard against unbounded solves (sliding along a discontinuity)
-    bool pend_f = false;          // f(yc) of the last accepted step has not been evaluated yet
-    bool jac_after_fnew = false;  // that step also asked for a fresh Jacobian (radau.py:500,512)
+    int attempts = 0;   // guard against unbounded solves (sliding along a discontinuity): see limit_hit
+    // pend_f: f(yc) of the last accepted step has not been evaluated yet
+    // jac_after_fnew: that step also asked for a fresh Jacobian (radau.py:500,512)
     int phase = PH_OUTER_BEGIN;
     long long diag_trips = 0, diag_newton = 0, diag_fact = 0, diag_jac = 0, diag_f3 = 0;
 #ifdef WT_STAMPS  // diagnostic build only: shader-clock shares of the loop's sections (never in the product .so)
@@ -1163,8 +1175,9 @@ __global__ __launch_bounds__(64) void step_kernel(const StepArgs a)
         // ================= finite-difference Jacobian at (yc, f) when a phase asked for it
         if (__ballot(need_jac) != 0ull) diag_jac++;
         if (need_jac) {
-            bool jbad = false;
-            num_jac<ROW>(L, k, yc, f, fac, have_fac, J, jbad); cnt.njev++;
+            bool jbad = false, hf = have_fac;
+            num_jac<ROW>(L, k, yc, f, fac, hf, J, jbad); cnt.njev++;
+            have_fac = hf;
             need_jac = false;
             if (seg_any(L, jbad)) { bad = true; phase = PH_OUTER_END; }
         }
