@@ -105,6 +105,10 @@ struct StepArgs {
 struct Lane {
     int n, z;
     bool has_lo, has_hi;
+    // the same neighbour tests as all-ones / zero words, one pair per cyclic-reduction stride 2^l: masking
+    // with a VGPR operand (v_and) keeps the tests out of the scalar register file, where each would be a
+    // 64-bit lane mask for the whole solver loop
+    uint32_t m_lo[7], m_hi[7];
     int base;                 // lane id of zone 0 of this segment
     unsigned long long segmask;
 };
@@ -140,6 +144,11 @@ template <bool ROW, int S> __device__ __forceinline__ double from_hi(double x)
 __device__ __forceinline__ double keep_if(bool valid, double x)
 {
     return __hiloint2double(valid ? __double2hiint(x) : 0, __double2loint(x));
+}
+
+__device__ __forceinline__ double keep_m(uint32_t mask, double x)
+{
+    return __hiloint2double(__double2hiint(x) & (int)mask, __double2loint(x));
 }
 
 __device__ __forceinline__ bool seg_any(const Lane &L, bool p) { return (__ballot(p) & L.segmask) != 0ull; }
@@ -309,12 +318,12 @@ __device__ __forceinline__ void rhs_rows(const Lane &L, const RK &k, double H, d
         s = k.supp;
     }
     const double k_hi = k.Kex_hi * s;                     // K[i,i+1]  reactor.py:321-325 (0 above the top zone)
-    const double k_lo = keep_if(L.has_lo, from_lo<ROW, 1>(k_hi)); // K[i,i-1] (bound_ctrl gives 0 below zone 0 of lane 0)
+    const double k_lo = keep_m(L.m_lo[0], from_lo<ROW, 1>(k_hi)); // K[i,i-1] (bound_ctrl gives 0 below zone 0 of lane 0)
     const double kd = -(k_lo + k_hi) - k.Qv_out;          // reactor.py:329-337
 
-    const double H_lo = keep_if(L.has_lo, from_lo<ROW, 1>(H)), H_hi = keep_if(L.has_hi, from_hi<ROW, 1>(H));
-    const double C_lo = keep_if(L.has_lo, from_lo<ROW, 1>(Cl)), C_hi = keep_if(L.has_hi, from_hi<ROW, 1>(Cl));
-    const double T_lo = keep_if(L.has_lo, from_lo<ROW, 1>(T)), T_hi = keep_if(L.has_hi, from_hi<ROW, 1>(T));
+    const double H_lo = keep_m(L.m_lo[0], from_lo<ROW, 1>(H)), H_hi = keep_m(L.m_hi[0], from_hi<ROW, 1>(H));
+    const double C_lo = keep_m(L.m_lo[0], from_lo<ROW, 1>(Cl)), C_hi = keep_m(L.m_hi[0], from_hi<ROW, 1>(Cl));
+    const double T_lo = keep_m(L.m_lo[0], from_lo<ROW, 1>(T)), T_hi = keep_m(L.m_hi[0], from_hi<ROW, 1>(T));
     // K @ x with OpenBLAS' accumulation order: neighbours first, diagonal last.  k_lo / k_hi are
     // exactly 0 where there is no neighbour, and what was read there is finite (keep_if).
     const double mixH = (k_lo * H_lo + k_hi * H_hi) + kd * H;
@@ -398,9 +407,9 @@ __device__ __forceinline__ void pcr_factor_level_all(const Lane &L, double ar[3]
         // themselves once the foreign operands are finite
         const double al = ar[k] * rcp(vlo ? d_lo : 1.0);
         const double ga = cr[k] * rcp(vhi ? d_hi : 1.0);
-        dr[k] = dr[k] - al * keep_if(vlo, c_lo) - ga * keep_if(vhi, a_hi);
-        ar[k] = -al * keep_if(vlo, a_lo);
-        cr[k] = -ga * keep_if(vhi, c_hi);
+        dr[k] = dr[k] - al * keep_m(L.m_lo[l], c_lo) - ga * keep_m(L.m_hi[l], a_hi);
+        ar[k] = -al * keep_m(L.m_lo[l], a_lo);
+        cr[k] = -ga * keep_m(L.m_hi[l], c_hi);
         F.st(k * S::RS + 2 * l, al); F.st(k * S::RS + 2 * l + 1, ga);
     }
 #pragma unroll
@@ -409,15 +418,15 @@ __device__ __forceinline__ void pcr_factor_level_all(const Lane &L, double ar[3]
         const cplx d_lo = cfrom_lo<ROW, s>(dc[k]), d_hi = cfrom_hi<ROW, s>(dc[k]);
         const cplx a_lo = cfrom_lo<ROW, s>(ac[k]), c_lo = cfrom_lo<ROW, s>(cc[k]);
         const cplx a_hi = cfrom_hi<ROW, s>(ac[k]), c_hi = cfrom_hi<ROW, s>(cc[k]);
-        const cplx dl = {vlo ? d_lo.r : 1.0, keep_if(vlo, d_lo.i)};
-        const cplx dh = {vhi ? d_hi.r : 1.0, keep_if(vhi, d_hi.i)};
+        const cplx dl = {vlo ? d_lo.r : 1.0, keep_m(L.m_lo[l], d_lo.i)};
+        const cplx dh = {vhi ? d_hi.r : 1.0, keep_m(L.m_hi[l], d_hi.i)};
         const cplx al = cmul(ac[k], cinv(dl));
         const cplx ga = cmul(cc[k], cinv(dh));
-        const cplx t1 = cmul(al, {keep_if(vlo, c_lo.r), keep_if(vlo, c_lo.i)});
-        const cplx t2 = cmul(ga, {keep_if(vhi, a_hi.r), keep_if(vhi, a_hi.i)});
+        const cplx t1 = cmul(al, {keep_m(L.m_lo[l], c_lo.r), keep_m(L.m_lo[l], c_lo.i)});
+        const cplx t2 = cmul(ga, {keep_m(L.m_hi[l], a_hi.r), keep_m(L.m_hi[l], a_hi.i)});
         dc[k] = {dc[k].r - t1.r - t2.r, dc[k].i - t1.i - t2.i};
-        const cplx na = cmul(al, {keep_if(vlo, a_lo.r), keep_if(vlo, a_lo.i)});
-        const cplx nc = cmul(ga, {keep_if(vhi, c_hi.r), keep_if(vhi, c_hi.i)});
+        const cplx na = cmul(al, {keep_m(L.m_lo[l], a_lo.r), keep_m(L.m_lo[l], a_lo.i)});
+        const cplx nc = cmul(ga, {keep_m(L.m_hi[l], c_hi.r), keep_m(L.m_hi[l], c_hi.i)});
         ac[k] = {-na.r, -na.i};
         cc[k] = {-nc.r, -nc.i};
         const int c0 = S::CB + k * S::CS + 4 * l;
@@ -457,9 +466,8 @@ template <bool ROW, int LV, int l>
 __device__ __forceinline__ void pcr_real_level(const Lane &L, const RealFactors<LV> &s, double &b)
 {
     constexpr int st = 1 << l;
-    const bool vlo = L.z - st >= 0, vhi = L.z + st < L.n;
     const double b_lo = from_lo<ROW, st>(b), b_hi = from_hi<ROW, st>(b);
-    b = b - s.a[l] * keep_if(vlo, b_lo) - s.g[l] * keep_if(vhi, b_hi);
+    b = b - s.a[l] * keep_m(L.m_lo[l], b_lo) - s.g[l] * keep_m(L.m_hi[l], b_hi);
     if constexpr (l + 1 < LV) pcr_real_level<ROW, LV, l + 1>(L, s, b);
 }
 
@@ -479,7 +487,7 @@ __device__ __forceinline__ void solve_real(const Lane &L, const Jac &J, const FS
     pcr_real_level<ROW, LV, 0>(L, fT, xT);
     xT *= fT.inv;
     const double xT_lo_r = from_lo<ROW, 1>(xT), xT_hi_r = from_hi<ROW, 1>(xT);
-    const double xT_lo = keep_if(L.has_lo, xT_lo_r), xT_hi = keep_if(L.has_hi, xT_hi_r); // J.pt/ct[0,2] are 0 there
+    const double xT_lo = keep_m(L.m_lo[0], xT_lo_r), xT_hi = keep_m(L.m_hi[0], xT_hi_r); // J.pt/ct[0,2] are 0 there
     double xP = b[SPH] + (J.pt[0] * xT_lo + J.pt[1] * xT + J.pt[2] * xT_hi);
     pcr_real_level<ROW, LV, 0>(L, fP, xP);
     xP *= fP.inv;
@@ -514,10 +522,9 @@ template <bool ROW, int LV, int l>
 __device__ __forceinline__ void pcr_rc_level(const Lane &L, const SysFactors<LV> &s, double &b, cplx &c)
 {
     constexpr int st = 1 << l;
-    const bool vlo = L.z - st >= 0, vhi = L.z + st < L.n;
-    const double b_lo = keep_if(vlo, from_lo<ROW, st>(b)), b_hi = keep_if(vhi, from_hi<ROW, st>(b));
-    const cplx c_lo = {keep_if(vlo, from_lo<ROW, st>(c.r)), keep_if(vlo, from_lo<ROW, st>(c.i))};
-    const cplx c_hi = {keep_if(vhi, from_hi<ROW, st>(c.r)), keep_if(vhi, from_hi<ROW, st>(c.i))};
+    const double b_lo = keep_m(L.m_lo[l], from_lo<ROW, st>(b)), b_hi = keep_m(L.m_hi[l], from_hi<ROW, st>(b));
+    const cplx c_lo = {keep_m(L.m_lo[l], from_lo<ROW, st>(c.r)), keep_m(L.m_lo[l], from_lo<ROW, st>(c.i))};
+    const cplx c_hi = {keep_m(L.m_hi[l], from_hi<ROW, st>(c.r)), keep_m(L.m_hi[l], from_hi<ROW, st>(c.i))};
     b = b - s.ra[l] * b_lo - s.rg[l] * b_hi;
     const cplx t1 = cmul(s.ca[l], c_lo), t2 = cmul(s.cg[l], c_hi);
     c = {c.r - t1.r - t2.r, c.i - t1.i - t2.i};
@@ -536,9 +543,9 @@ __device__ __forceinline__ void solve_rc(const Lane &L, const Jac &J, const FSto
     pcr_rc_level<ROW, LV, 0>(L, sT, xT, zT);
     xT *= sT.rinv; zT = cmul(zT, sT.cinv);
     load_sys<LV>(F, 2, sC);
-    const double xT_lo = keep_if(L.has_lo, from_lo<ROW, 1>(xT)), xT_hi = keep_if(L.has_hi, from_hi<ROW, 1>(xT));
-    const cplx zT_lo = {keep_if(L.has_lo, from_lo<ROW, 1>(zT.r)), keep_if(L.has_lo, from_lo<ROW, 1>(zT.i))};
-    const cplx zT_hi = {keep_if(L.has_hi, from_hi<ROW, 1>(zT.r)), keep_if(L.has_hi, from_hi<ROW, 1>(zT.i))};
+    const double xT_lo = keep_m(L.m_lo[0], from_lo<ROW, 1>(xT)), xT_hi = keep_m(L.m_hi[0], from_hi<ROW, 1>(xT));
+    const cplx zT_lo = {keep_m(L.m_lo[0], from_lo<ROW, 1>(zT.r)), keep_m(L.m_lo[0], from_lo<ROW, 1>(zT.i))};
+    const cplx zT_hi = {keep_m(L.m_hi[0], from_hi<ROW, 1>(zT.r)), keep_m(L.m_hi[0], from_hi<ROW, 1>(zT.i))};
     // pH block: rhs += J_pT x_T
     double xP = br[SPH] + (J.pt[0] * xT_lo + J.pt[1] * xT + J.pt[2] * xT_hi);
     cplx zP = {cr[SPH] + (J.pt[0] * zT_lo.r + J.pt[1] * zT.r + J.pt[2] * zT_hi.r),
@@ -777,6 +784,14 @@ __device__ __forceinline__ bool lane_setup(int64_t r0, int64_t r1, int n, int R,
     L.n = n; L.z = lane - seg * n;
     L.base = seg * n;
     L.has_lo = L.z > 0; L.has_hi = L.z < n - 1;
+#pragma unroll
+    for (int l = 0; l < 7; ++l) {
+        L.m_lo[l] = (L.z - (1 << l) >= 0) ? ~0u : 0u;
+        L.m_hi[l] = (L.z + (1 << l) < n) ? ~0u : 0u;
+        // opaque to the optimiser, or `x & mask` is canonicalised back into a select on the compare
+        asm("" : "+v"(L.m_lo[l]));
+        asm("" : "+v"(L.m_hi[l]));
+    }
     L.segmask = ((n >= 64) ? ~0ull : ((1ull << n) - 1ull)) << L.base;
     r = r0 + (int64_t)blockIdx.x * R + seg;
     return (seg < R) && (r < r1);
