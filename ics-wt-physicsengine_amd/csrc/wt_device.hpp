@@ -422,9 +422,16 @@ __device__ __forceinline__ void pcr_factor_level_all(const Lane &L, double ar[3]
         const cplx dh = {vhi ? d_hi.r : 1.0, keep_m(L.m_hi[l], d_hi.i)};
         const cplx al = cmul(ac[k], cinv(dl));
         const cplx ga = cmul(cc[k], cinv(dh));
-        const cplx t1 = cmul(al, {keep_m(L.m_lo[l], c_lo.r), keep_m(L.m_lo[l], c_lo.i)});
-        const cplx t2 = cmul(ga, {keep_m(L.m_hi[l], a_hi.r), keep_m(L.m_hi[l], a_hi.i)});
-        dc[k] = {dc[k].r - t1.r - t2.r, dc[k].i - t1.i - t2.i};
+        {   // d -= al * c_lo + ga * a_hi, eight fused multiply-adds
+            const cplx cl = {keep_m(L.m_lo[l], c_lo.r), keep_m(L.m_lo[l], c_lo.i)};
+            const cplx ah = {keep_m(L.m_hi[l], a_hi.r), keep_m(L.m_hi[l], a_hi.i)};
+            double dre = dc[k].r, dim = dc[k].i;
+            dre = __builtin_fma(-al.r, cl.r, dre); dim = __builtin_fma(-al.r, cl.i, dim);
+            dre = __builtin_fma(al.i, cl.i, dre);  dim = __builtin_fma(-al.i, cl.r, dim);
+            dre = __builtin_fma(-ga.r, ah.r, dre); dim = __builtin_fma(-ga.r, ah.i, dim);
+            dre = __builtin_fma(ga.i, ah.i, dre);  dim = __builtin_fma(-ga.i, ah.r, dim);
+            dc[k] = {dre, dim};
+        }
         const cplx na = cmul(al, {keep_m(L.m_lo[l], a_lo.r), keep_m(L.m_lo[l], a_lo.i)});
         const cplx nc = cmul(ga, {keep_m(L.m_hi[l], c_hi.r), keep_m(L.m_hi[l], c_hi.i)});
         ac[k] = {-na.r, -na.i};
@@ -526,8 +533,13 @@ __device__ __forceinline__ void pcr_rc_level(const Lane &L, const SysFactors<LV>
     const cplx c_lo = {keep_m(L.m_lo[l], from_lo<ROW, st>(c.r)), keep_m(L.m_lo[l], from_lo<ROW, st>(c.i))};
     const cplx c_hi = {keep_m(L.m_hi[l], from_hi<ROW, st>(c.r)), keep_m(L.m_hi[l], from_hi<ROW, st>(c.i))};
     b = b - s.ra[l] * b_lo - s.rg[l] * b_hi;
-    const cplx t1 = cmul(s.ca[l], c_lo), t2 = cmul(s.cg[l], c_hi);
-    c = {c.r - t1.r - t2.r, c.i - t1.i - t2.i};
+    // c -= ca * c_lo + cg * c_hi as eight fused multiply-adds (no separate products and subtractions)
+    double cr = c.r, ci = c.i;
+    cr = __builtin_fma(-s.ca[l].r, c_lo.r, cr); ci = __builtin_fma(-s.ca[l].r, c_lo.i, ci);
+    cr = __builtin_fma(s.ca[l].i, c_lo.i, cr);  ci = __builtin_fma(-s.ca[l].i, c_lo.r, ci);
+    cr = __builtin_fma(-s.cg[l].r, c_hi.r, cr); ci = __builtin_fma(-s.cg[l].r, c_hi.i, ci);
+    cr = __builtin_fma(s.cg[l].i, c_hi.i, cr);  ci = __builtin_fma(-s.cg[l].i, c_hi.r, ci);
+    c = {cr, ci};
     if constexpr (l + 1 < LV) pcr_rc_level<ROW, LV, l + 1>(L, s, b, c);
 }
 
