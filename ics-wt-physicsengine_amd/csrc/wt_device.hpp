@@ -109,6 +109,7 @@ struct Lane {
     // with a VGPR operand (v_and) keeps the tests out of the scalar register file, where each would be a
     // 64-bit lane mask for the whole solver loop
     uint32_t m_lo[7], m_hi[7];
+    int a_lo[7], a_hi[7];     // ds_bpermute byte addresses of lane -/+ 2^l (segments that straddle DPP rows)
     int base;                 // lane id of zone 0 of this segment
     unsigned long long segmask;
 };
@@ -125,17 +126,25 @@ template <int CTRL> __device__ __forceinline__ double dpp_mov(double x)
 // every power-of-two stride is a row shift.  ROW = false: any n <= 64; stride 1
 // is a whole-wave DPP shift, larger strides go through ds_bpermute.
 // Values read from outside the segment are unspecified; callers mask them.
-template <bool ROW, int S> __device__ __forceinline__ double from_lo(double x)
+__device__ __forceinline__ double bpermute(int byte_addr, double x)
+{
+    const int lo = __builtin_amdgcn_ds_bpermute(byte_addr, __double2loint(x));
+    const int hi = __builtin_amdgcn_ds_bpermute(byte_addr, __double2hiint(x));
+    return __hiloint2double(hi, lo);
+}
+constexpr int ilog2(int s) { return s <= 1 ? 0 : 1 + ilog2(s >> 1); }
+
+template <bool ROW, int S> __device__ __forceinline__ double from_lo(const Lane &L, double x)
 {   // value held by lane (this - S)
     if constexpr (ROW && S < 16) return dpp_mov<0x110 + S>(x);      // row_shr:S
     else if constexpr (S == 1) return dpp_mov<0x138>(x);  // wave_shr:1
-    else return __shfl_up(x, S, 64);
+    else return bpermute(L.a_lo[ilog2(S)], x);
 }
-template <bool ROW, int S> __device__ __forceinline__ double from_hi(double x)
+template <bool ROW, int S> __device__ __forceinline__ double from_hi(const Lane &L, double x)
 {   // value held by lane (this + S)
     if constexpr (ROW && S < 16) return dpp_mov<0x100 + S>(x);      // row_shl:S
     else if constexpr (S == 1) return dpp_mov<0x130>(x);  // wave_shl:1
-    else return __shfl_down(x, S, 64);
+    else return bpermute(L.a_hi[ilog2(S)], x);
 }
 
 // A value read from outside the segment only ever meets a zero coefficient, so it is
@@ -308,7 +317,7 @@ __device__ __forceinline__ void rhs_rows(const Lane &L, const RK &k, double H, d
 {
     // mixing suppression of the interface above this zone (spatial.py:239-320):
     // Ri = g drho dz / (rho_avg u^2) > Ri_crit  <=>  g dz drho > Ri_crit u^2 rho_avg
-    const double rho_hi = from_hi<ROW, 1>(rho);
+    const double rho_hi = from_hi<ROW, 1>(L, rho);
     double s = 1.0;
     if (k.strat_mode == 1) {
         const double drho = rho_hi - rho;
@@ -318,12 +327,12 @@ __device__ __forceinline__ void rhs_rows(const Lane &L, const RK &k, double H, d
         s = k.supp;
     }
     const double k_hi = k.Kex_hi * s;                     // K[i,i+1]  reactor.py:321-325 (0 above the top zone)
-    const double k_lo = keep_m(L.m_lo[0], from_lo<ROW, 1>(k_hi)); // K[i,i-1] (bound_ctrl gives 0 below zone 0 of lane 0)
+    const double k_lo = keep_m(L.m_lo[0], from_lo<ROW, 1>(L, k_hi)); // K[i,i-1] (bound_ctrl gives 0 below zone 0 of lane 0)
     const double kd = -(k_lo + k_hi) - k.Qv_out;          // reactor.py:329-337
 
-    const double H_lo = keep_m(L.m_lo[0], from_lo<ROW, 1>(H)), H_hi = keep_m(L.m_hi[0], from_hi<ROW, 1>(H));
-    const double C_lo = keep_m(L.m_lo[0], from_lo<ROW, 1>(Cl)), C_hi = keep_m(L.m_hi[0], from_hi<ROW, 1>(Cl));
-    const double T_lo = keep_m(L.m_lo[0], from_lo<ROW, 1>(T)), T_hi = keep_m(L.m_hi[0], from_hi<ROW, 1>(T));
+    const double H_lo = keep_m(L.m_lo[0], from_lo<ROW, 1>(L, H)), H_hi = keep_m(L.m_hi[0], from_hi<ROW, 1>(L, H));
+    const double C_lo = keep_m(L.m_lo[0], from_lo<ROW, 1>(L, Cl)), C_hi = keep_m(L.m_hi[0], from_hi<ROW, 1>(L, Cl));
+    const double T_lo = keep_m(L.m_lo[0], from_lo<ROW, 1>(L, T)), T_hi = keep_m(L.m_hi[0], from_hi<ROW, 1>(L, T));
     // K @ x with OpenBLAS' accumulation order: neighbours first, diagonal last.  k_lo / k_hi are
     // exactly 0 where there is no neighbour, and what was read there is finite (keep_if).
     const double mixH = (k_lo * H_lo + k_hi * H_hi) + kd * H;
@@ -384,8 +393,8 @@ struct cplx { double r, i; };
 __device__ __forceinline__ cplx cmul(cplx a, cplx b) { return {a.r * b.r - a.i * b.i, a.r * b.i + a.i * b.r}; }
 __device__ __forceinline__ cplx cinv(cplx a) { const double q = rcp(a.r * a.r + a.i * a.i); return {a.r * q, -a.i * q}; }
 
-template <bool ROW, int S> __device__ __forceinline__ cplx cfrom_lo(cplx a) { return {from_lo<ROW, S>(a.r), from_lo<ROW, S>(a.i)}; }
-template <bool ROW, int S> __device__ __forceinline__ cplx cfrom_hi(cplx a) { return {from_hi<ROW, S>(a.r), from_hi<ROW, S>(a.i)}; }
+template <bool ROW, int S> __device__ __forceinline__ cplx cfrom_lo(const Lane &L, cplx a) { return {from_lo<ROW, S>(L, a.r), from_lo<ROW, S>(L, a.i)}; }
+template <bool ROW, int S> __device__ __forceinline__ cplx cfrom_hi(const Lane &L, cplx a) { return {from_hi<ROW, S>(L, a.r), from_hi<ROW, S>(L, a.i)}; }
 
 // One cyclic-reduction level of all six systems (three real, three complex shift) at once: the
 // six eliminations are independent, so issuing them together hides the reciprocal / DPP latency
@@ -400,9 +409,9 @@ __device__ __forceinline__ void pcr_factor_level_all(const Lane &L, double ar[3]
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         // real shift
-        const double d_lo = from_lo<ROW, s>(dr[k]), d_hi = from_hi<ROW, s>(dr[k]);
-        const double a_lo = from_lo<ROW, s>(ar[k]), c_lo = from_lo<ROW, s>(cr[k]);
-        const double a_hi = from_hi<ROW, s>(ar[k]), c_hi = from_hi<ROW, s>(cr[k]);
+        const double d_lo = from_lo<ROW, s>(L, dr[k]), d_hi = from_hi<ROW, s>(L, dr[k]);
+        const double a_lo = from_lo<ROW, s>(L, ar[k]), c_lo = from_lo<ROW, s>(L, cr[k]);
+        const double a_hi = from_hi<ROW, s>(L, ar[k]), c_hi = from_hi<ROW, s>(L, cr[k]);
         // a == 0 where there is no lower neighbour (c likewise), so alpha/gamma vanish there by
         // themselves once the foreign operands are finite
         const double al = ar[k] * rcp(vlo ? d_lo : 1.0);
@@ -415,9 +424,9 @@ __device__ __forceinline__ void pcr_factor_level_all(const Lane &L, double ar[3]
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         // complex shift
-        const cplx d_lo = cfrom_lo<ROW, s>(dc[k]), d_hi = cfrom_hi<ROW, s>(dc[k]);
-        const cplx a_lo = cfrom_lo<ROW, s>(ac[k]), c_lo = cfrom_lo<ROW, s>(cc[k]);
-        const cplx a_hi = cfrom_hi<ROW, s>(ac[k]), c_hi = cfrom_hi<ROW, s>(cc[k]);
+        const cplx d_lo = cfrom_lo<ROW, s>(L, dc[k]), d_hi = cfrom_hi<ROW, s>(L, dc[k]);
+        const cplx a_lo = cfrom_lo<ROW, s>(L, ac[k]), c_lo = cfrom_lo<ROW, s>(L, cc[k]);
+        const cplx a_hi = cfrom_hi<ROW, s>(L, ac[k]), c_hi = cfrom_hi<ROW, s>(L, cc[k]);
         const cplx dl = {vlo ? d_lo.r : 1.0, keep_m(L.m_lo[l], d_lo.i)};
         const cplx dh = {vhi ? d_hi.r : 1.0, keep_m(L.m_hi[l], d_hi.i)};
         const cplx al = cmul(ac[k], cinv(dl));
@@ -473,7 +482,7 @@ template <bool ROW, int LV, int l>
 __device__ __forceinline__ void pcr_real_level(const Lane &L, const RealFactors<LV> &s, double &b)
 {
     constexpr int st = 1 << l;
-    const double b_lo = from_lo<ROW, st>(b), b_hi = from_hi<ROW, st>(b);
+    const double b_lo = from_lo<ROW, st>(L, b), b_hi = from_hi<ROW, st>(L, b);
     b = b - s.a[l] * keep_m(L.m_lo[l], b_lo) - s.g[l] * keep_m(L.m_hi[l], b_hi);
     if constexpr (l + 1 < LV) pcr_real_level<ROW, LV, l + 1>(L, s, b);
 }
@@ -493,7 +502,7 @@ __device__ __forceinline__ void solve_real(const Lane &L, const Jac &J, const FS
     double xT = b[STT];
     pcr_real_level<ROW, LV, 0>(L, fT, xT);
     xT *= fT.inv;
-    const double xT_lo_r = from_lo<ROW, 1>(xT), xT_hi_r = from_hi<ROW, 1>(xT);
+    const double xT_lo_r = from_lo<ROW, 1>(L, xT), xT_hi_r = from_hi<ROW, 1>(L, xT);
     const double xT_lo = keep_m(L.m_lo[0], xT_lo_r), xT_hi = keep_m(L.m_hi[0], xT_hi_r); // J.pt/ct[0,2] are 0 there
     double xP = b[SPH] + (J.pt[0] * xT_lo + J.pt[1] * xT + J.pt[2] * xT_hi);
     pcr_real_level<ROW, LV, 0>(L, fP, xP);
@@ -529,9 +538,9 @@ template <bool ROW, int LV, int l>
 __device__ __forceinline__ void pcr_rc_level(const Lane &L, const SysFactors<LV> &s, double &b, cplx &c)
 {
     constexpr int st = 1 << l;
-    const double b_lo = keep_m(L.m_lo[l], from_lo<ROW, st>(b)), b_hi = keep_m(L.m_hi[l], from_hi<ROW, st>(b));
-    const cplx c_lo = {keep_m(L.m_lo[l], from_lo<ROW, st>(c.r)), keep_m(L.m_lo[l], from_lo<ROW, st>(c.i))};
-    const cplx c_hi = {keep_m(L.m_hi[l], from_hi<ROW, st>(c.r)), keep_m(L.m_hi[l], from_hi<ROW, st>(c.i))};
+    const double b_lo = keep_m(L.m_lo[l], from_lo<ROW, st>(L, b)), b_hi = keep_m(L.m_hi[l], from_hi<ROW, st>(L, b));
+    const cplx c_lo = {keep_m(L.m_lo[l], from_lo<ROW, st>(L, c.r)), keep_m(L.m_lo[l], from_lo<ROW, st>(L, c.i))};
+    const cplx c_hi = {keep_m(L.m_hi[l], from_hi<ROW, st>(L, c.r)), keep_m(L.m_hi[l], from_hi<ROW, st>(L, c.i))};
     b = b - s.ra[l] * b_lo - s.rg[l] * b_hi;
     // c -= ca * c_lo + cg * c_hi as eight fused multiply-adds (no separate products and subtractions)
     double cr = c.r, ci = c.i;
@@ -555,9 +564,9 @@ __device__ __forceinline__ void solve_rc(const Lane &L, const Jac &J, const FSto
     pcr_rc_level<ROW, LV, 0>(L, sT, xT, zT);
     xT *= sT.rinv; zT = cmul(zT, sT.cinv);
     load_sys<LV>(F, 2, sC);
-    const double xT_lo = keep_m(L.m_lo[0], from_lo<ROW, 1>(xT)), xT_hi = keep_m(L.m_hi[0], from_hi<ROW, 1>(xT));
-    const cplx zT_lo = {keep_m(L.m_lo[0], from_lo<ROW, 1>(zT.r)), keep_m(L.m_lo[0], from_lo<ROW, 1>(zT.i))};
-    const cplx zT_hi = {keep_m(L.m_hi[0], from_hi<ROW, 1>(zT.r)), keep_m(L.m_hi[0], from_hi<ROW, 1>(zT.i))};
+    const double xT_lo = keep_m(L.m_lo[0], from_lo<ROW, 1>(L, xT)), xT_hi = keep_m(L.m_hi[0], from_hi<ROW, 1>(L, xT));
+    const cplx zT_lo = {keep_m(L.m_lo[0], from_lo<ROW, 1>(L, zT.r)), keep_m(L.m_lo[0], from_lo<ROW, 1>(L, zT.i))};
+    const cplx zT_hi = {keep_m(L.m_hi[0], from_hi<ROW, 1>(L, zT.r)), keep_m(L.m_hi[0], from_hi<ROW, 1>(L, zT.i))};
     // pH block: rhs += J_pT x_T
     double xP = br[SPH] + (J.pt[0] * xT_lo + J.pt[1] * xT + J.pt[2] * xT_hi);
     cplx zP = {cr[SPH] + (J.pt[0] * zT_lo.r + J.pt[1] * zT.r + J.pt[2] * zT_hi.r),
@@ -654,8 +663,8 @@ __device__ __forceinline__ void fd_col_reduce(const Lane &L, const FdCols &c, do
         if (!dep_own) continue;
         double d_lo = 0, s_lo = 0, d_hi = 0, s_hi = 0;
         if (dep_nb) {
-            d_lo = from_lo<ROW, 1>(c.D[q][2]); s_lo = from_lo<ROW, 1>(c.S[q][2]); // lane z-1 saw this column at rel=+1
-            d_hi = from_hi<ROW, 1>(c.D[q][0]); s_hi = from_hi<ROW, 1>(c.S[q][0]); // lane z+1 saw it at rel=-1
+            d_lo = from_lo<ROW, 1>(L, c.D[q][2]); s_lo = from_lo<ROW, 1>(L, c.S[q][2]); // lane z-1 saw this column at rel=+1
+            d_hi = from_hi<ROW, 1>(L, c.D[q][0]); s_hi = from_hi<ROW, 1>(L, c.S[q][0]); // lane z+1 saw it at rel=-1
         }
         if (dep_nb && L.has_lo && fabs(d_lo) > maxd) { maxd = fabs(d_lo); scale = s_lo; }
         if (fabs(c.D[q][1]) > maxd) { maxd = fabs(c.D[q][1]); scale = c.S[q][1]; }
@@ -704,7 +713,7 @@ __device__ __forceinline__ void num_jac_species(const Lane &L, const RK &k, cons
         }
     }
     // diff /= h (column-wise; the column's h lives in the column's lane)
-    const double h_lo = from_lo<ROW, 1>(h), h_hi = from_hi<ROW, 1>(h);
+    const double h_lo = from_lo<ROW, 1>(L, h), h_hi = from_hi<ROW, 1>(L, h);
     const double ih0 = L.has_lo ? rcp(h_lo) : 0.0, ih1 = rcp(h), ih2 = L.has_hi ? rcp(h_hi) : 0.0;
 #pragma unroll
     for (int q = 0; q < 3; ++q) { cols.D[q][0] *= ih0; cols.D[q][1] *= ih1; cols.D[q][2] *= ih2; }
@@ -800,6 +809,7 @@ __device__ __forceinline__ bool lane_setup(int64_t r0, int64_t r1, int n, int R,
     for (int l = 0; l < 7; ++l) {
         L.m_lo[l] = (L.z - (1 << l) >= 0) ? ~0u : 0u;
         L.m_hi[l] = (L.z + (1 << l) < n) ? ~0u : 0u;
+        L.a_lo[l] = ((lane - (1 << l)) & 63) << 2; L.a_hi[l] = ((lane + (1 << l)) & 63) << 2;
         // opaque to the optimiser, or `x & mask` is canonicalised back into a select on the compare
         asm("" : "+v"(L.m_lo[l]));
         asm("" : "+v"(L.m_hi[l]));
@@ -1274,10 +1284,10 @@ __global__ __launch_bounds__(64) void shuffle_selftest_kernel(const ShuffleTestA
     const double x = 1000.0 * (lane + 1) + 0.5;
     int bad = 0;
     auto chk = [&](double got, int src, bool valid) { if (valid && got != 1000.0 * (src + 1) + 0.5) bad++; };
-    chk(from_lo<ROW, 1>(x), lane - 1, L.z >= 1); chk(from_hi<ROW, 1>(x), lane + 1, L.z + 1 < L.n);
-    chk(from_lo<ROW, 2>(x), lane - 2, L.z >= 2); chk(from_hi<ROW, 2>(x), lane + 2, L.z + 2 < L.n);
-    chk(from_lo<ROW, 4>(x), lane - 4, L.z >= 4); chk(from_hi<ROW, 4>(x), lane + 4, L.z + 4 < L.n);
-    chk(from_lo<ROW, 8>(x), lane - 8, L.z >= 8); chk(from_hi<ROW, 8>(x), lane + 8, L.z + 8 < L.n);
+    chk(from_lo<ROW, 1>(L, x), lane - 1, L.z >= 1); chk(from_hi<ROW, 1>(L, x), lane + 1, L.z + 1 < L.n);
+    chk(from_lo<ROW, 2>(L, x), lane - 2, L.z >= 2); chk(from_hi<ROW, 2>(L, x), lane + 2, L.z + 2 < L.n);
+    chk(from_lo<ROW, 4>(L, x), lane - 4, L.z >= 4); chk(from_hi<ROW, 4>(L, x), lane + 4, L.z + 4 < L.n);
+    chk(from_lo<ROW, 8>(L, x), lane - 8, L.z >= 8); chk(from_hi<ROW, 8>(L, x), lane + 8, L.z + 8 < L.n);
     double ref = 0.0;
     for (int j = 0; j < L.n; ++j) ref += 1000.0 * (L.base + j + 1) + 0.5; // exact in fp64 (small integers + halves)
     if (seg_sum<ROW>(L, x) != ref) bad++;
