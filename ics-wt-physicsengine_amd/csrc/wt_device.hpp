@@ -149,12 +149,8 @@ template <bool ROW, int S> __device__ __forceinline__ double from_hi(const Lane 
 
 // A value read from outside the segment only ever meets a zero coefficient, so it is
 // enough to make it FINITE: clearing the high dword (sign, exponent, top mantissa bits)
-// turns any NaN/Inf another reactor may hold into a denormal.  One v_cndmask per read.
-__device__ __forceinline__ double keep_if(bool valid, double x)
-{
-    return __hiloint2double(valid ? __double2hiint(x) : 0, __double2loint(x));
-}
-
+// turns any NaN/Inf another reactor may hold into a denormal.  One v_and per read (with the
+// Lane's all-ones / zero mask words), which the compiler folds into the DPP move of that dword.
 __device__ __forceinline__ double keep_m(uint32_t mask, double x)
 {
     return __hiloint2double(__double2hiint(x) & (int)mask, __double2loint(x));
@@ -334,7 +330,7 @@ __device__ __forceinline__ void rhs_rows(const Lane &L, const RK &k, double H, d
     const double C_lo = keep_m(L.m_lo[0], from_lo<ROW, 1>(L, Cl)), C_hi = keep_m(L.m_hi[0], from_hi<ROW, 1>(L, Cl));
     const double T_lo = keep_m(L.m_lo[0], from_lo<ROW, 1>(L, T)), T_hi = keep_m(L.m_hi[0], from_hi<ROW, 1>(L, T));
     // K @ x with OpenBLAS' accumulation order: neighbours first, diagonal last.  k_lo / k_hi are
-    // exactly 0 where there is no neighbour, and what was read there is finite (keep_if).
+    // exactly 0 where there is no neighbour, and what was read there is finite (keep_m).
     const double mixH = (k_lo * H_lo + k_hi * H_hi) + kd * H;
     const double mixC = (k_lo * C_lo + k_hi * C_hi) + kd * Cl;
     const double mixT = (k_lo * T_lo + k_hi * T_hi) + kd * T;
