@@ -264,6 +264,35 @@ __device__ __forceinline__ void mask_reactor_for_lane(const Lane &L, RK &k)
     k.UAr_on = k.has_heat ? k.UAr : 0.0;
 }
 
+// The constants are needed by the RHS evaluations only.  Between them (factorisation, Newton solve, error
+// estimate) they would occupy 38 VGPRs of a register file that is already oversubscribed, so they are parked
+// in LDS and fetched at the top of every RHS block: 14 per-reactor words (one copy per reactor, broadcast to
+// its lanes) and 5 per-lane ones.
+constexpr int RK_UNI = 14, RK_LANE = 5, RK_MAXR = 32;   // up to 32 reactors per wavefront (n = 2)
+struct RKStore { double *uni; double *lane; };          // uni[c * RK_MAXR], lane[c * 64]: already offset for this lane
+
+__device__ __forceinline__ void park_reactor(const RKStore &st, const RK &k)
+{
+    const double u[RK_UNI] = {k.Kw, k.Ka1, k.Ka1Ka2, k.KaH, k.cbeta, k.gdz, k.rcu2, k.supp, k.H_in, k.Cl_in, k.T_in, k.T_amb, k.UAr_on,
+                              (double)k.strat_mode};
+    const double l[RK_LANE] = {k.Kex_hi, k.Qv_in, k.Qv_out, k.acid0, k.dose0};
+#pragma unroll
+    for (int c = 0; c < RK_UNI; ++c) st.uni[c * RK_MAXR] = u[c];     // every lane of the reactor stores the same value
+#pragma unroll
+    for (int c = 0; c < RK_LANE; ++c) st.lane[c * 64] = l[c];
+}
+
+__device__ __forceinline__ RK fetch_reactor(const RKStore &st)
+{
+    RK k;
+    k.Kw = st.uni[0 * RK_MAXR]; k.Ka1 = st.uni[1 * RK_MAXR]; k.Ka1Ka2 = st.uni[2 * RK_MAXR]; k.KaH = st.uni[3 * RK_MAXR];
+    k.cbeta = st.uni[4 * RK_MAXR]; k.gdz = st.uni[5 * RK_MAXR]; k.rcu2 = st.uni[6 * RK_MAXR]; k.supp = st.uni[7 * RK_MAXR];
+    k.H_in = st.uni[8 * RK_MAXR]; k.Cl_in = st.uni[9 * RK_MAXR]; k.T_in = st.uni[10 * RK_MAXR]; k.T_amb = st.uni[11 * RK_MAXR];
+    k.UAr_on = st.uni[12 * RK_MAXR]; k.strat_mode = (int)st.uni[13 * RK_MAXR];
+    k.Kex_hi = st.lane[0 * 64]; k.Qv_in = st.lane[1 * 64]; k.Qv_out = st.lane[2 * 64]; k.acid0 = st.lane[3 * 64]; k.dose0 = st.lane[4 * 64];
+    return k;
+}
+
 // ---------------------------------------------------------------- zone-local properties
 struct PropPH { double H, iw, phi; bool bpos; }; // iw = 1/(beta*ln10)
 struct PropT { double kT, rho; bool bad; };
@@ -824,7 +853,12 @@ __global__ __launch_bounds__(64) void step_kernel(const StepArgs a)
     uint32_t st = a.status[r];
     // a reactor whose last step raised stays frozen until the host rewrites its state
     if (st & (ST_T_RANGE | ST_T_RANGE_POST)) { if (a.tap_count && L.z == 0) a.tap_count[r] = 0; return; }
-    RK k; load_reactor(a.par, a.bc, a.N, r, a.n, k); mask_reactor_for_lane(L, k);
+    __shared__ double lds_rk[RK_UNI * RK_MAXR + RK_LANE * 64];
+    const RKStore ks = {lds_rk + (threadIdx.x & 63) / a.n, lds_rk + RK_UNI * RK_MAXR + (threadIdx.x & 63)};
+    {
+        RK k0; load_reactor(a.par, a.bc, a.N, r, a.n, k0); mask_reactor_for_lane(L, k0);
+        park_reactor(ks, k0);
+    }
 
     // ---- per-reactor state (segment-uniform scalars are replicated in every lane)
     double y0[3] = {a.pH[idx], a.Cl[idx], a.T[idx]}; // state at the start of the outer step
@@ -1060,6 +1094,7 @@ __global__ __launch_bounds__(64) void step_kernel(const StepArgs a)
             if (newton) p0 = yc[q] + z0;
             ye[0][q] = p0; ye[1][q] = yc[q] + z1; ye[2][q] = yc[q] + z2;
         }
+        const RK k = fetch_reactor(ks);
         if (__ballot(newton) != 0ull) {
             // some reactor of the wavefront is in its Newton phase: all three stage points in one
             // straight-line block (three independent chains for the scheduler to interleave); the
@@ -1209,7 +1244,9 @@ __global__ __launch_bounds__(64) void step_kernel(const StepArgs a)
         if (__ballot(need_jac) != 0ull) diag_jac++;
         if (need_jac) {
             bool jbad = false, hf = have_fac;
-            num_jac<ROW>(L, k, yc, f, fac, hf, J, jbad); cnt.njev++;
+            asm volatile("" ::: "memory");               // a fresh fetch: do not keep the constants live across the epilogue
+            const RK kj = fetch_reactor(ks);
+            num_jac<ROW>(L, kj, yc, f, fac, hf, J, jbad); cnt.njev++;
             have_fac = hf;
             need_jac = false;
             if (seg_any(L, jbad)) { bad = true; phase = PH_OUTER_END; }
