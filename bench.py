@@ -32,6 +32,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+DEFAULT_CHUNK = 50     # outer steps per launch (the library's default schedule, WT_DEFAULT_CHUNK)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
@@ -80,7 +81,7 @@ def main() -> int:
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--reactors", type=int, default=10000, help="reactors per GPU")
     ap.add_argument("--zones", type=int, default=8)
-    ap.add_argument("--chunk", type=int, default=25,
+    ap.add_argument("--chunk", type=int, default=DEFAULT_CHUNK,
                     help="outer steps per kernel launch (1 = one launch per outer step)")
     ap.add_argument("--streams", type=int, default=0,
                     help="reactor ranges / HIP streams per GPU (0 = library default: min(4, wavefronts/64))")
@@ -135,7 +136,7 @@ def main() -> int:
         if use_dist:
             dist.barrier()
 
-    if args.streams > 0 or args.chunk != 25:
+    if args.streams > 0 or args.chunk != DEFAULT_CHUNK:
         waves = -(-N // (64 // n))
         ens.set_schedule(args.streams if args.streams > 0 else max(1, min(4, waves // 64)), max(1, args.chunk))
     n_streams = args.streams if args.streams > 0 else max(1, min(4, (-(-N // (64 // n))) // 64))
@@ -191,7 +192,7 @@ def main() -> int:
         # HBM traffic per launch measured offline with rocprofv3 PMC passes for this exact workload
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "r1", "traffic.json")
-        if os.path.exists(tpath) and (N, n, args.chunk, n_streams) == (10000, 8, 25, 4):
+        if os.path.exists(tpath) and (N, n, args.chunk, n_streams) == (10000, 8, DEFAULT_CHUNK, 4):
             with open(tpath) as fh:
                 traffic = json.load(fh).get("traffic_bytes_per_launch")
         out = {
@@ -212,7 +213,7 @@ def main() -> int:
                             f"{args.chunk} outer step(s) per launch, {n_streams} reactor range(s)/stream(s)"
                             + (" + fused fp32 sensor suite" if args.sensors else "")
                             + (" + Modbus register image / command path per launch" if args.plant_io else ""),
-                "reactors_per_gpu": N, "zones": n, "dt_s": 1.0,
+                "reactors_per_gpu": N, "zones": n, "dt_s": 1.0, "steps_per_launch": args.chunk,
                 "sharding": f"instance-parallel x{world}, final RCCL all_gather only",
             },
             "roofline": {

@@ -56,7 +56,7 @@ struct wt_ensemble {
     // Reactors are independent, so the hardware queues interleave the ranges' wavefronts:
     // a range whose launch ends in a slow wavefront only delays its own next launch, and
     // 1250 wavefronts of work no longer take two full rounds on 1024 SIMDs.
-    int n_sub = 1, chunk_steps = 25;
+    int n_sub = 1, chunk_steps = WT_DEFAULT_CHUNK;
     int sync_outer = 1;
     int step_limit = 2000;    // attempts per outer step before a reactor is given up (reference: unlimited)
     hipStream_t sub_stream[WT_MAX_STREAMS] = {};
@@ -237,7 +237,7 @@ int wt_ensemble_create(int64_t n_reactors, int n_zones, int device, const double
         const int64_t waves = (n_reactors + h->R - 1) / h->R;
         int ns = (int)(waves / 64);
         h->n_sub = ns < 1 ? 1 : (ns > 4 ? 4 : ns);
-        h->chunk_steps = 25;
+        h->chunk_steps = WT_DEFAULT_CHUNK;
     }
     hipError_t e = hipMemcpyAsync(h->par, par, sizeof(double) * WT_NP * N, hipMemcpyHostToDevice, h->stream);
     if (e == hipSuccess) e = hipMemsetAsync(h->status, 0, sizeof(uint32_t) * N, h->stream);

@@ -30,6 +30,7 @@ extern "C" {
 #define WT_ABI_VERSION 1
 #define WT_MAX_ZONES 64 /* one reactor's zones live in one 64-lane wavefront */
 #define WT_MAX_STREAMS 8
+#define WT_DEFAULT_CHUNK 50   /* outer steps per launch unless wt_ensemble_set_schedule says otherwise */
 
 /* rows of the per-reactor constant block (values as the reference's __init__
  * computes them: reactor.py:229-270, chemistry.py:116-132, transport.py:202-290) */
@@ -103,7 +104,7 @@ int wt_ensemble_step(wt_ensemble *h, double dt, int n_steps, int fused);
 /* Launch schedule: the ensemble is advanced as n_streams contiguous reactor ranges
  * on internal HIP streams (fork/join around the handle's stream), at most
  * chunk_steps outer steps per launch (0 = the whole call in one launch).
- * Default: min(4, wavefronts/64) ranges, 25 steps. */
+ * Default: min(4, wavefronts/64) ranges, WT_DEFAULT_CHUNK steps. */
 int wt_ensemble_set_schedule(wt_ensemble *h, int n_streams, int chunk_steps);
 /* sync_outer != 0: the reactors sharing a wavefront start every outer step together (they wait
  * for the slowest of them) so that their Jacobian / factorisation / Newton work coincides.

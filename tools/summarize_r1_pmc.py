@@ -30,13 +30,13 @@ summ["dispatch_meta"] = meta
 fetch, write = summ["FETCH_SIZE"]["mean_per_launch"] * 1024.0, summ["WRITE_SIZE"]["mean_per_launch"] * 1024.0
 summ["traffic_bytes_per_launch"] = {"fetch": fetch, "write": write, "total": fetch + write,
     "note": "FETCH_SIZE/WRITE_SIZE (KiB) x 1024, separate --pmc passes. 8 B/lane accesses: the gfx950 half-count correction of MI355X_MICROARCH.md is calibrated for 16 B/lane streams only, so the read side may be under-counted by up to 2x."}
-waves = summ["SQ_WAVES"]["mean_per_launch"]; steps = 25
+waves = summ["SQ_WAVES"]["mean_per_launch"]; steps = bt["config"]["steps_per_launch"]
 summ["per_wavefront_step"] = {"valu_insts": summ["SQ_INSTS_VALU"]["mean_per_launch"] / waves / steps, "salu_insts": summ["SQ_INSTS_SALU"]["mean_per_launch"] / waves / steps,
     "lds_insts": summ["SQ_INSTS_LDS"]["mean_per_launch"] / waves / steps,
     "valu_busy_frac": summ["SQ_ACTIVE_INST_VALU"]["mean_per_launch"] / summ["SQ_WAVE_CYCLES"]["mean_per_launch"],
     "wait_any_frac": summ["SQ_WAIT_ANY"]["mean_per_launch"] / summ["SQ_WAVE_CYCLES"]["mean_per_launch"],
     "lane_utilisation": summ["SQ_THREAD_CYCLES_VALU"]["mean_per_launch"] / (64.0 * summ["SQ_ACTIVE_INST_VALU"]["mean_per_launch"])}
 json.dump(summ, open(os.path.join(P, "pmc_summary.json"), "w"), indent=1)
-json.dump({"traffic_bytes_per_launch": fetch + write, "fetch_bytes": fetch, "write_bytes": write, "workload": "10000 x 8, 25 steps/launch, 4 ranges",
+json.dump({"traffic_bytes_per_launch": fetch + write, "fetch_bytes": fetch, "write_bytes": write, "workload": "10000 x 8, %d steps/launch, 4 ranges" % bt["config"]["steps_per_launch"],
            "source": "profiles/r1/pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"}, open(os.path.join(P, "traffic.json"), "w"), indent=1)
 print(json.dumps(agree, indent=1)); print(json.dumps(summ["per_wavefront_step"], indent=1)); print(fetch, write)
