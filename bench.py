@@ -91,8 +91,8 @@ def main() -> int:
                     help="also keep the per-reactor Modbus register images and run the command path once per launch "
                          "(--chunk 1 = one PLC scan per outer step, as the reference loop); implies --sensors")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-reactors", type=int, default=4096)
-    ap.add_argument("--cpu-sample-steps", type=int, default=100)
+    ap.add_argument("--cpu-sample-reactors", type=int, default=8192)
+    ap.add_argument("--cpu-sample-steps", type=int, default=600)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
