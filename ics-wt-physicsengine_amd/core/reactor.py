@@ -579,19 +579,25 @@ class IntegratedCSTR:
             raise ValueError(f"Unknown parameter: {parameter}")
         return table[parameter][zone_idx]
 
+    def _device_diagnostics(self) -> Dict[str, np.ndarray]:
+        s = self.state
+        self._ens.set_state(np.asarray(s.pH, dtype=np.float64)[None, :], np.asarray(s.chlorine, dtype=np.float64)[None, :],
+                            np.asarray(s.temperature, dtype=np.float64)[None, :], np.array([s.time], dtype=np.float64))
+        return self._ens.diagnostics()
+
     def validate_conservation(self) -> Dict[str, float]:
-        """Mass / charge / energy inventory (reactor.py:570-611)."""
-        zone_volume = self.config.volume / self.config.n_zones
-        total_chlorine_mg = np.sum(self.state.chlorine) * zone_volume
-        total_H_mol = np.sum(self.state.H_concentration) * zone_volume / 1000
-        Kw = float(params.water_ionization_constant(np.array([self.state.temperature[0]]))[0])
-        total_OH_mol = np.sum(Kw / self.state.H_concentration) * zone_volume / 1000
-        V_m3 = self.config.volume / 1000
-        thermal_energy_kJ = 998.2 * 4184 * V_m3 * np.mean(self.state.temperature - 20.0) / 1000
-        return {"total_chlorine_mg": total_chlorine_mg, "total_H_mol": total_H_mol,
-                "total_OH_mol": total_OH_mol, "charge_balance_mol": total_H_mol - total_OH_mol,
-                "thermal_energy_kJ": thermal_energy_kJ, "zones": self.config.n_zones,
-                "timestamp": self.state.time}
+        """Mass / charge / energy inventory of ``self.state`` (reactor.py:570-611), reduced on the device."""
+        d = self._device_diagnostics()
+        out = {k: float(d[k][0]) for k in ("total_chlorine_mg", "total_H_mol", "total_OH_mol", "charge_balance_mol", "thermal_energy_kJ")}
+        out["zones"] = self.config.n_zones
+        out["timestamp"] = self.state.time
+        return out
+
+    def mixing_quality(self) -> Dict[str, float]:
+        """(CV, segregation index) of pH and chlorine as ``print_diagnostics`` reports them
+        (transport.py:338-384 via reactor.py:638-639)."""
+        d = self._device_diagnostics()
+        return {k: float(d[k][0]) for k in ("pH_CV", "pH_segregation", "chlorine_CV", "chlorine_segregation")}
 
 
 PhysicsEngine = IntegratedCSTR  # the name BASELINE.json uses for this API

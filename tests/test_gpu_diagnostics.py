@@ -48,3 +48,22 @@ def test_diagnostics_after_steps_vs_oracle(gpu, wt, n):
     # conservation sanity: chlorine mass = mean concentration x volume
     assert np.allclose(out[:, 0], es.chlorine.mean(1) * 1000.0, rtol=1e-13)
     ens.close()
+
+
+def test_dropin_validate_conservation_vs_reference(gpu, wt):
+    """IntegratedCSTR.validate_conservation / mixing_quality of the single-reactor drop-in (same keys as the
+    reference's dict) on golden states"""
+    g = golden_npz("g9_diag_n8.npz")
+    for i in (0, 3, 6, 11):
+        kw = {k[4:]: float(g[k][i]) for k in g.files if k.startswith("cfg_")}
+        cfg = wt.ReactorConfiguration(n_zones=8, enable_thermal_stratification=bool(g["strat"][i]), **kw)
+        r = wt.IntegratedCSTR(cfg)
+        st = g["state"][i]
+        r.state.pH, r.state.chlorine, r.state.temperature = st[0].copy(), st[1].copy(), st[2].copy()
+        c = r.validate_conservation()
+        ref = g["diag"][i]
+        assert list(c) == ["total_chlorine_mg", "total_H_mol", "total_OH_mol", "charge_balance_mol", "thermal_energy_kJ", "zones", "timestamp"]
+        assert c["total_chlorine_mg"] == ref[0] and c["thermal_energy_kJ"] == ref[4] and c["zones"] == 8
+        assert abs(c["total_H_mol"] - ref[1]) <= 1e-15 * abs(ref[1]) and abs(c["total_OH_mol"] - ref[2]) <= 1e-15 * abs(ref[2])
+        m = r.mixing_quality()
+        assert (m["pH_CV"], m["pH_segregation"], m["chlorine_CV"], m["chlorine_segregation"]) == tuple(ref[5:9])
