@@ -600,4 +600,23 @@ class IntegratedCSTR:
         return {k: float(d[k][0]) for k in ("pH_CV", "pH_segregation", "chlorine_CV", "chlorine_segregation")}
 
 
+    def print_diagnostics(self) -> None:
+        """The report of reactor.py:613-645 (numbers from the device diagnostics)."""
+        d = self._device_diagnostics()
+        s, n = self.state, self.config.n_zones
+        print("\n" + "=" * 70 + "\nCSTR PHYSICS DIAGNOSTICS\n" + "=" * 70)
+        print(f"\nTime: {s.time:.1f} s")
+        print(f"Residence time: {self.transport.residence_time:.1f} min")
+        print(f"\n{'Zone':<6} {'pH':<8} {'Cl(mg/L)':<10} {'T(°C)':<8} {'ρ(kg/m³)':<10}\n" + "-" * 50)
+        for i in range(n):
+            print(f"{i:<6} {s.pH[i]:<8.3f} {s.chlorine[i]:<10.3f} {s.temperature[i]:<8.2f} {s.density[i]:<10.2f}")
+        print("\nConservation Laws:")
+        print(f"  Total Chlorine: {d['total_chlorine_mg'][0]:.2f} mg")
+        print(f"  Charge Balance: {d['charge_balance_mol'][0]:.2e} mol")
+        print("\nMixing Quality:")
+        print(f"  pH segregation index: {d['pH_segregation'][0]:.4f}")
+        print(f"  Chlorine segregation index: {d['chlorine_segregation'][0]:.4f}")
+        print("=" * 70 + "\n")
+
+
 PhysicsEngine = IntegratedCSTR  # the name BASELINE.json uses for this API
