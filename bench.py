@@ -195,6 +195,20 @@ def main() -> int:
         if os.path.exists(tpath) and (N, n, args.chunk, n_streams) == (10000, 8, DEFAULT_CHUNK, 4):
             with open(tpath) as fh:
                 traffic = json.load(fh).get("traffic_bytes_per_launch")
+        # secondary, compute-side roofline: the kernel is bound by fp64 VALU issue, not by HBM.  Peak = what the
+        # chip's SIMDs can issue (one fp64 VALU instruction per 4 cycles per SIMD) divided by the measured VALU
+        # instruction count per wavefront-step of this kernel (rocprofv3 SQ_INSTS_VALU / SQ_WAVES / steps).
+        compute = None
+        ppath = os.path.join(ROOT, "profiles", "r1", "pmc_summary.json")
+        if os.path.exists(ppath) and n == 8:
+            with open(ppath) as fh:
+                valu = json.load(fh).get("per_wavefront_step", {}).get("valu_insts")
+            if valu:
+                peak = 256 * 4 * 2.4e9 / 4.0 / valu * 64.0 * world
+                compute = {"bound": "fp64 VALU issue", "achieved": value, "peak": peak, "unit": "reactor-zone-steps/s",
+                           "frac": value / peak, "valu_insts_per_wavefront_step": valu,
+                           "source": "profiles/r1/pmc_summary.json (SQ_INSTS_VALU / SQ_WAVES / steps per launch); "
+                                     "peak = 1024 SIMDs x 2.4 GHz / 4 cycles per fp64 VALU op / insts x 64 zones"}
         out = {
             "metric": "reactor-zone-steps/sec",
             "value": value,
@@ -235,6 +249,7 @@ def main() -> int:
                 "note": "path is fp64-VALU/latency bound (adaptive implicit solve per reactor), not HBM bound; "
                         "see DESIGN.md roofline section",
             },
+            "roofline_compute": compute,
             "sensors": ({"suite": "7 sensors/reactor (pH in/out, Cl amperometric/DPD, magnetic flow, RTD in/out), fp32, "
                                   "one read per outer step, Philox4x32-10 streams",
                          "readings_per_s": world * N * 7 * args.steps / elapsed} if args.sensors else None),
