@@ -81,8 +81,9 @@ def main() -> int:
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--reactors", type=int, default=10000, help="reactors per GPU")
     ap.add_argument("--zones", type=int, default=8)
-    ap.add_argument("--chunk", type=int, default=DEFAULT_CHUNK,
-                    help="outer steps per kernel launch (1 = one launch per outer step)")
+    ap.add_argument("--chunk", type=int, default=0,
+                    help="outer steps per kernel launch (1 = one launch per outer step; 0 = the library default of "
+                         "50, shortened for short runs so that every reactor range still gets several launches)")
     ap.add_argument("--streams", type=int, default=0,
                     help="reactor ranges / HIP streams per GPU (0 = library default: min(4, wavefronts/64))")
     ap.add_argument("--sensors", action="store_true",
@@ -95,6 +96,8 @@ def main() -> int:
     ap.add_argument("--cpu-sample-steps", type=int, default=600)
     args = ap.parse_args()
 
+    if args.chunk <= 0:      # a launch lasts as long as its slowest wavefront: keep >= 4 launches per range (2 for tiny runs)
+        args.chunk = min(DEFAULT_CHUNK, max(1, -(-args.steps // (4 if args.steps > 50 else 2))))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
