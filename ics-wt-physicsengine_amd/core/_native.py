@@ -73,6 +73,9 @@ def lib():
     L.wt_ensemble_set_boundary.argtypes = [vp, dp]
     L.wt_ensemble_step.argtypes = [vp, C.c_double, C.c_int, C.c_int]
     L.wt_ensemble_set_schedule.argtypes = [vp, C.c_int, C.c_int]
+    ip = C.POINTER(C.c_int)
+    L.wt_ensemble_get_schedule.argtypes = [vp, ip, ip, ip, ip]
+    L.wt_ensemble_get_schedule.restype = C.c_int
     L.wt_ensemble_set_sync.argtypes = [vp, C.c_int]
     L.wt_ensemble_set_step_limit.argtypes = [vp, C.c_int]
     L.wt_ensemble_launch_timing.argtypes = [vp, C.c_int]

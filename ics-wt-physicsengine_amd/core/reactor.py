@@ -277,10 +277,19 @@ class ReactorEnsemble:
             raise
         return self.state if download else None
 
-    def set_schedule(self, n_streams: int, chunk_steps: int = 25) -> None:
+    def set_schedule(self, n_streams: int = 0, chunk_steps: int = 50) -> None:
         """Advance the ensemble as ``n_streams`` contiguous reactor ranges on internal HIP
-        streams, at most ``chunk_steps`` outer steps per launch (0 = one launch per call)."""
+        streams (0 = the library default), at most ``chunk_steps`` outer steps per launch
+        (0 = one launch per call)."""
         _native.check(_native.lib().wt_ensemble_set_schedule(self._h, int(n_streams), int(chunk_steps)))
+
+    def schedule(self) -> Dict[str, object]:
+        """The schedule in force: {"mode", "streams", "chunk", "workers", "kernel"}."""
+        m, s, c, w = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)
+        _native.check(_native.lib().wt_ensemble_get_schedule(self._h, C.byref(m), C.byref(s), C.byref(c), C.byref(w)))
+        mode = {0: "streams", 1: "queue"}.get(m.value, str(m.value))
+        return {"mode": mode, "streams": s.value, "chunk": c.value, "workers": w.value,
+                "kernel": "wt::step_kernel" if mode == "streams" else "wt::step_worker_kernel"}
 
     def set_step_limit(self, max_attempts: int) -> None:
         """Stop a reactor that needs more than ``max_attempts`` Radau step attempts in one outer step

@@ -116,6 +116,14 @@ void release_plc_buffers(wt_ensemble *h)
 
 bool row_mode(int n) { return n == 2 || n == 4 || n == 8 || n == 16; }
 
+// default stream schedule: up to 4 ranges, but keep at least 64 wavefronts per range
+int default_streams(int64_t n_reactors, int R)
+{
+    const int64_t waves = (n_reactors + R - 1) / R;
+    const int ns = (int)(waves / 64);
+    return ns < 1 ? 1 : (ns > 4 ? 4 : ns);
+}
+
 void launch_step_raw(const wt_ensemble *h, const wt::StepArgs &a, hipStream_t stream);
 
 // the rest of one pass of the reference's loop body after reactor.step, for the reactors of this launch:
@@ -233,12 +241,8 @@ int wt_ensemble_create(int64_t n_reactors, int n_zones, int device, const double
     h->own_stream = true;
     if (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) { cleanup(); return fail(WT_E_HIP, "hipEventCreate failed"); }
     if (hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess) { cleanup(); return fail(WT_E_HIP, "hipEventCreate failed"); }
-    {   // default schedule: up to 4 ranges, but keep at least 64 wavefronts per range
-        const int64_t waves = (n_reactors + h->R - 1) / h->R;
-        int ns = (int)(waves / 64);
-        h->n_sub = ns < 1 ? 1 : (ns > 4 ? 4 : ns);
-        h->chunk_steps = WT_DEFAULT_CHUNK;
-    }
+    h->n_sub = default_streams(n_reactors, h->R);
+    h->chunk_steps = WT_DEFAULT_CHUNK;
     hipError_t e = hipMemcpyAsync(h->par, par, sizeof(double) * WT_NP * N, hipMemcpyHostToDevice, h->stream);
     if (e == hipSuccess) e = hipMemsetAsync(h->status, 0, sizeof(uint32_t) * N, h->stream);
     if (e == hipSuccess) e = hipMemsetAsync(h->stats, 0, sizeof(int32_t) * 5 * N, h->stream);
@@ -586,9 +590,20 @@ int wt_ensemble_set_sync(wt_ensemble *h, int sync_outer)
 int wt_ensemble_set_schedule(wt_ensemble *h, int n_streams, int chunk_steps)
 {
     if (!h) return fail(WT_E_ARG, "NULL handle");
-    if (n_streams < 1 || n_streams > WT_MAX_STREAMS) return fail(WT_E_ARG, "n_streams out of range");
+    if (n_streams < 0 || n_streams > WT_MAX_STREAMS) return fail(WT_E_ARG, "n_streams out of range");
     if (chunk_steps < 0) return fail(WT_E_ARG, "chunk_steps must be >= 0 (0 = whole call in one launch)");
-    h->n_sub = n_streams; h->chunk_steps = chunk_steps;
+    h->n_sub = n_streams > 0 ? n_streams : default_streams(h->N, h->R);
+    h->chunk_steps = chunk_steps;
+    return WT_OK;
+}
+
+int wt_ensemble_get_schedule(wt_ensemble *h, int *mode, int *n_streams, int *chunk_steps, int *workers)
+{
+    if (!h) return fail(WT_E_ARG, "NULL handle");
+    if (mode) *mode = WT_SCHED_STREAMS;
+    if (n_streams) *n_streams = h->n_sub;
+    if (chunk_steps) *chunk_steps = h->chunk_steps;
+    if (workers) *workers = 0;
     return WT_OK;
 }
 

@@ -106,6 +106,10 @@ int wt_ensemble_step(wt_ensemble *h, double dt, int n_steps, int fused);
  * chunk_steps outer steps per launch (0 = the whole call in one launch).
  * Default: min(4, wavefronts/64) ranges, WT_DEFAULT_CHUNK steps. */
 int wt_ensemble_set_schedule(wt_ensemble *h, int n_streams, int chunk_steps);
+/* the schedule in force: mode (WT_SCHED_*), reactor ranges / streams, outer steps per launch or work
+ * item, and worker wavefronts of the persistent schedule (0 under WT_SCHED_STREAMS) */
+enum { WT_SCHED_STREAMS = 0, WT_SCHED_QUEUE = 1 };
+int wt_ensemble_get_schedule(wt_ensemble *h, int *mode, int *n_streams, int *chunk_steps, int *workers);
 /* sync_outer != 0: the reactors sharing a wavefront start every outer step together (they wait
  * for the slowest of them) so that their Jacobian / factorisation / Newton work coincides.
  * Results are unaffected; it is a throughput knob. */

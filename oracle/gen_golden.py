@@ -15,6 +15,12 @@ Fixture families:
   g4_faults.json        ValueError step index of a freezing run, TypeError on batch construction
   g5_ph_solver.json     AqueousChemistry.calculate_pH / add_acid / add_base
   g6_ensemble_n{n}.npz  first 64 reactors of the synthetic ensemble, 50 steps
+  g10_outliers_n{n}.npz reactors of the 10k / 12.5k bench ensembles on which two correct executions of the
+                        solver drift apart (indices from tools/outlier_scan.py on the GPU box and
+                        tools/oracle_self_sensitivity.py here): 100 steps of the reference itself
+  g11_branches.npz/json branches no other family reaches: clamps (reactor.py:526-541), host-edited state
+                        between steps (:467-469), velocity scale <= 1e-6 -> Ri = inf (spatial.py:270-275),
+                        non-finite state (solve_ivp refuses it: ValueError out of step())
 """
 from __future__ import annotations
 
@@ -229,9 +235,136 @@ def g6():
                             every=every, steps=steps, n_reactors=S)
 
 
+def _run_reference(cfg, b, steps, dt=1.0, edits=None):
+    """step() `steps` times; edits = {step index: callable(state)} applied BEFORE that step.
+    Returns per-step state (steps + 1, 3, n), derived (steps, 3, n), time, flow, scipy counters."""
+    r = IntegratedCSTR(cfg)
+    n = cfg.n_zones
+    _stats.clear()
+    traj = np.empty((steps + 1, 3, n)); der = np.empty((steps, 3, n)); times = []; flows = []
+    pre = np.empty((steps, 3, n)); pre_t = []
+    traj[0] = [r.state.pH, r.state.chlorine, r.state.temperature]
+    for k in range(steps):
+        if edits and k in edits:
+            edits[k](r.state)
+        pre[k] = [r.state.pH, r.state.chlorine, r.state.temperature]; pre_t.append(r.state.time)
+        s = r.step(dt, b)
+        traj[k + 1] = [s.pH, s.chlorine, s.temperature]
+        der[k] = [s.H_concentration, s.density, s.chlorine_decay_rate]
+        times.append(s.time); flows.append(s.flow_rate)
+    return dict(traj=traj, pre=pre, pre_time=np.array(pre_t), derived=der, time=np.array(times), flow=np.array(flows),
+                stats=np.array(_stats, dtype=np.int32))
+
+
+def g10():
+    """Reference trajectories of the reactors on which the solver's step sequence is sensitive to
+    rounding (where the GPU and the CPU oracle, or two variants of the oracle, differ by > 1e-7)."""
+    with open(os.path.join(OUT, "g10_outlier_indices.json")) as f:
+        idx = json.load(f)
+    steps, every = 100, 10
+    for key, reactors in idx["reactors"].items():          # key = "n8", "n20", ...
+        n = int(key[1:])
+        reactors = sorted(int(x) for x in reactors)
+        if not reactors:
+            continue
+        cols, bc = wt.make_ensemble(max(reactors) + 1)
+        snaps = np.empty((len(reactors), steps // every, 3, n))
+        stats = np.empty((len(reactors), steps, 5), dtype=np.int32)
+        for j, r_i in enumerate(reactors):
+            cfg = ReactorConfiguration(n_zones=n, **{k: float(v[r_i]) for k, v in cols.items()})
+            b = BoundaryConditions(**{k: float(bc[i, r_i]) for i, k in enumerate(BC_FIELDS)})
+            out = _run_reference(cfg, b, steps)
+            snaps[j] = out["traj"][every::every]
+            stats[j] = out["stats"]
+            print(f"  g10 n={n} reactor {r_i} ({j + 1}/{len(reactors)})", flush=True)
+        np.savez_compressed(os.path.join(OUT, f"g10_outliers_n{n}.npz"), reactors=np.array(reactors, dtype=np.int64),
+                            snaps=snaps, stats=stats, every=every, steps=steps)
+
+
+def g11():
+    cases = {}
+    meta = {}
+
+    def put(name, cfg, b, out, dt=1.0):
+        for k, v in out.items():
+            cases[f"{name}__{k}"] = v
+        cases[f"{name}__cfg"] = np.array([getattr(cfg, k) for k in CFG_FIELDS], dtype=np.float64)
+        cases[f"{name}__bc"] = np.array(bc_to_vec(b))
+        meta[name] = {"n_zones": cfg.n_zones, "dt": dt, "steps": int(out["time"].shape[0])}
+
+    # clamps: the state is edited into a region the step cannot leave -> clip + log (reactor.py:526-541)
+    b0 = BoundaryConditions()
+    put("clamp_cl", ReactorConfiguration(n_zones=4), b0, _run_reference(
+        ReactorConfiguration(n_zones=4), b0, 3, edits={0: lambda s: setattr(s, "chlorine", np.full(4, -0.5))}))
+    put("clamp_ph_hi", ReactorConfiguration(n_zones=4), b0, _run_reference(
+        ReactorConfiguration(n_zones=4), b0, 3, edits={0: lambda s: setattr(s, "pH", np.array([14.5, 14.2, 7.0, 7.0]))}))
+    put("clamp_ph_lo", ReactorConfiguration(n_zones=4), b0, _run_reference(
+        ReactorConfiguration(n_zones=4), b0, 3, edits={0: lambda s: setattr(s, "pH", np.array([-0.5, 0.2, 7.0, 7.0]))}))
+    # host-edited state between steps, including the clock (reactor.py:467-472)
+    cfg8 = ReactorConfiguration(n_zones=8, initial_pH=7.4)
+    b8 = BoundaryConditions(acid_flow_rate=0.4, chlorine_flow_rate=0.3, inlet_temperature=24.0, heat_loss_coefficient=3.0,
+                            ambient_temperature=12.0)
+
+    def e5(s):
+        s.pH = np.linspace(6.8, 7.9, 8)
+
+    def e12(s):
+        s.chlorine = s.chlorine * np.array([1, 0.5, 2, 1, 1, 0.25, 1, 3.0]); s.temperature = s.temperature + np.linspace(-2, 2, 8)
+
+    def e20(s):
+        s.time = 1000.5; s.temperature[3] = 7.9995; s.temperature[4] = 8.0005     # straddles the 8 degC density branch
+
+    put("host_edit", cfg8, b8, _run_reference(cfg8, b8, 30, edits={5: e5, 12: e12, 20: e20}))
+    # velocity scale <= 1e-6 m/s: Ri = +inf, every interface "stable" (spatial.py:270-275)
+    for n in (4, 8):
+        cfgu = ReactorConfiguration(n_zones=n, flow_rate=0.02, temperature=18.0)
+        bu = BoundaryConditions(inlet_flow_rate=0.02, inlet_temperature=26.0, chlorine_flow_rate=0.5, heat_loss_coefficient=8.0,
+                                ambient_temperature=5.0)
+        r = IntegratedCSTR(cfgu)
+        assert r.transport.superficial_velocity <= 1e-6
+        put(f"low_u_n{n}", cfgu, bu, _run_reference(cfgu, bu, 60))
+    # RHS at random states of a u <= 1e-6 reactor (strat on/off)
+    rng = np.random.default_rng(1111)
+    ys, fs, cfgs, bcs = [], [], [], []
+    for case in range(64):
+        n = 8
+        cfg = ReactorConfiguration(n_zones=n, flow_rate=float(rng.uniform(0.001, 0.029)), temperature=float(rng.uniform(5, 35)),
+                                   enable_thermal_stratification=bool(case % 5 != 0))
+        r = IntegratedCSTR(cfg)
+        assert r.transport.superficial_velocity <= 1e-6
+        b = BoundaryConditions(inlet_flow_rate=float(rng.uniform(0, 0.05)), inlet_pH=float(rng.uniform(6, 9)),
+                               inlet_temperature=float(rng.uniform(5, 35)), acid_flow_rate=float(rng.choice([0.0, 0.7])),
+                               heat_loss_coefficient=float(rng.choice([0.0, 4.0])))
+        y = np.concatenate([rng.uniform(5.5, 9.5, n), rng.uniform(0, 4, n), rng.uniform(2, 38, n)])
+        ys.append(y); fs.append(r.derivatives(0.0, y, b)); cfgs.append([getattr(cfg, k) for k in CFG_FIELDS]); bcs.append(bc_to_vec(b))
+    cases["rhs_low_u__y"] = np.array(ys); cases["rhs_low_u__f"] = np.array(fs)
+    cases["rhs_low_u__cfg"] = np.array(cfgs, dtype=np.float64); cases["rhs_low_u__bc"] = np.array(bcs)
+    cases["cfg_fields"] = np.array(CFG_FIELDS)
+    np.savez_compressed(os.path.join(OUT, "g11_branches.npz"), **cases)
+    # non-finite state: scipy's solve_ivp refuses it, the ValueError escapes step(), state untouched
+    r = IntegratedCSTR(ReactorConfiguration(n_zones=4))
+    r.step(1.0, b0)
+    before = [r.state.pH.tolist(), r.state.chlorine.tolist(), r.state.temperature.tolist(), r.state.time]
+    nf = {}
+    for label, val in (("nan", float("nan")), ("inf", float("inf"))):
+        r.state.pH = np.array([7.0, val, 7.0, 7.0])
+        try:
+            r.step(1.0, b0)
+            nf[label] = {"raised": None}
+        except ValueError as e:
+            nf[label] = {"raised": "ValueError", "message": str(e), "time_after": r.state.time}
+    meta["nonfinite"] = nf
+    # solver failure (reactor.py:486-490): not reachable with a finite state in any scenario tried
+    # (an adversarial search with the CPU oracle over 7500 reactor-configurations on the RHS's branches
+    # finds none; Radau's TOO_SMALL_STEP needs Newton to fail at every step size)
+    meta["solver_failure"] = "unreached in the reference with finite state; see DESIGN.md section 4"
+    with open(os.path.join(OUT, "g11_branches.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g10", "g11"]
     for name in which:
         print("generating", name, flush=True)
         globals()[name]()

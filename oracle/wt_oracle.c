@@ -768,6 +768,10 @@ int wto_step(int n, const double *par, const double *bc, double dt,
     static __thread radau_t R; static __thread lu_t L;
     R.have_old = 0; R.have_factor = 0; R.have_lu = 0; R.have_sol = 0; R.current_jac = 1;
 
+    /* scipy refuses a non-finite initial state (base.py:19-20 check_arguments: ValueError "All components
+     * of the initial state `y0` must be finite."); it escapes step(), self.state and the clock stay as they are */
+    for (int i = 0; i < m; i++) if (!isfinite(y[i])) return WTO_ST_NONFINITE;
+
     double t0 = *t, t_bound = *t + dt;           /* reactor.py:472 */
     double max_step = fmin(dt, 10.0);            /* reactor.py:480 */
     double newton_tol = fmax(10 * EPS / RTOL, fmin(0.03, pow(RTOL, 0.5)));
@@ -835,7 +839,7 @@ void wto_ensemble_step(int N, int n, const double *par, const double *bc, double
             int st = wto_step(n, par + (size_t)r * WTO_NP, bc + (size_t)r * WTO_NB, dt,
                               y + (size_t)r * m, t + r, derived ? derived + (size_t)r * m : NULL, NULL);
             if (status) status[r] |= st;
-            if (st & (WTO_ST_T_RANGE | WTO_ST_T_RANGE_POST)) break; /* reference raises; loop stops */
+            if (st & (WTO_ST_T_RANGE | WTO_ST_T_RANGE_POST | WTO_ST_NONFINITE)) break; /* reference raises; loop stops */
         }
     }
 }

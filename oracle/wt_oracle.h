@@ -54,7 +54,7 @@ enum {
     WTO_ST_CLAMP_CL = 8,      /* reactor.py:534-536 */
     WTO_ST_CLAMP_T = 16,      /* reactor.py:539-541 */
     WTO_ST_T_RANGE_POST = 32, /* ValueError from _update_derived_state reactor.py:522-524 */
-    WTO_ST_NONFINITE = 64,
+    WTO_ST_NONFINITE = 64,    /* non-finite state at the start of a step: scipy raises ValueError (base.py:19-20), state untouched */
     WTO_ST_STEP_LIMIT = 128   /* guard (not in the reference): attempt limit of wto_set_step_limit hit */
 };
 

@@ -162,3 +162,76 @@ def test_synthetic_ensemble_sample(wt, oracle, n):
         assert relerr(pH, snap[:, 0]) < 1e-7
         assert relerr(Cl, snap[:, 1]) < 1e-7
         assert relerr(T, snap[:, 2]) < 1e-7
+
+
+# ---------------------------------------------------------------- g11: branches no other family reaches
+BRANCH_CASES = ("clamp_cl", "clamp_ph_hi", "clamp_ph_lo", "host_edit", "low_u_n4", "low_u_n8")
+
+
+def branch_case(wt, name):
+    """(n, par, bc, dt, pre-state (steps, 3n), pre-time, post-state, derived, time, flow, stats) of a g11 case:
+    `pre` is self.state as the reference's step() found it (host edits included), `traj[k + 1]` what it left."""
+    g = golden_npz("g11_branches.npz")
+    meta = golden_json("g11_branches.json")[name]
+    n = meta["n_zones"]
+    cols = cfg_columns(g[f"{name}__cfg"], g["cfg_fields"])
+    par = wt.params.derive_constants(cols, n)[:, 0]
+    return dict(n=n, par=par, cols=cols, bc=g[f"{name}__bc"], dt=meta["dt"], pre=g[f"{name}__pre"], pre_time=g[f"{name}__pre_time"],
+                traj=g[f"{name}__traj"], derived=g[f"{name}__derived"], time=g[f"{name}__time"], flow=g[f"{name}__flow"],
+                stats=g[f"{name}__stats"])
+
+
+@pytest.mark.parametrize("name", BRANCH_CASES)
+def test_branch_fixtures_oracle_vs_reference(wt, oracle, name):
+    """Clamps (reactor.py:526-541), host-edited state and clock between steps (:467-472), velocity scale
+    <= 1e-6 -> Ri = inf (spatial.py:270-275): every step started from the reference's own pre-step state."""
+    c = branch_case(wt, name)
+    n = c["n"]
+    expect_flags = {"clamp_cl": oracle.ST_CLAMP_CL, "clamp_ph_hi": oracle.ST_CLAMP_PH, "clamp_ph_lo": oracle.ST_CLAMP_PH}
+    for k in range(c["pre"].shape[0]):
+        y, t, der, status, st = oracle.step(n, c["par"], c["bc"], c["dt"], c["pre"][k].reshape(-1), float(c["pre_time"][k]),
+                                            want_stats=True)
+        post = c["traj"][k + 1].reshape(-1)
+        tol = 1e-7 if name == "clamp_ph_lo" and k == 0 else 1e-9     # 80 internal steps through pH 0..2
+        assert np.all(np.abs(y - post) <= tol * np.abs(post) + 1e-300), f"{name} step {k}"
+        assert t == c["time"][k]
+        assert (st.nfev, st.njev, st.nlu, st.nsteps) == tuple(c["stats"][k][:4]), f"{name} step {k}"
+        assert relerr(der.reshape(3, n), c["derived"][k]) < 10 * tol
+        if k == 0 and name in expect_flags:
+            assert status == expect_flags[name]
+            # the clip really happened in the reference: the post-state sits on the bound
+            assert (post[n:2 * n] == 0).all() if name == "clamp_cl" else ((post[:n] == 14.0).any() or (post[:n] == 0.0).any())
+        elif name not in expect_flags:
+            assert status == 0
+
+
+def test_low_velocity_rhs_matches_reference(wt, oracle):
+    """u <= 1e-6 m/s: calculate_richardson_number returns +inf, every interface is suppressed."""
+    g = golden_npz("g11_branches.npz")
+    n = 8
+    cols = cfg_columns(g["rhs_low_u__cfg"], g["cfg_fields"])
+    par = wt.params.derive_constants(cols, n)
+    assert np.all(par[wt.params.P_USUP] <= 1e-6)
+    for c in range(g["rhs_low_u__y"].shape[0]):
+        f, st = oracle.rhs(n, par[:, c], g["rhs_low_u__bc"][c], g["rhs_low_u__y"][c])
+        ref = g["rhs_low_u__f"][c]
+        assert st == 0
+        assert np.array_equal(f[2 * n:], ref[2 * n:]), f"case {c}"      # temperature rows: pure arithmetic
+        assert np.allclose(f[:2 * n], ref[:2 * n], rtol=1e-9, atol=1e-18), f"case {c}"
+
+
+def test_nonfinite_state_raises_like_reference(wt, oracle):
+    """scipy refuses a non-finite y0: ValueError out of step(), state and clock untouched."""
+    nf = golden_json("g11_branches.json")["nonfinite"]
+    assert nf["nan"]["raised"] == nf["inf"]["raised"] == "ValueError"
+    assert nf["nan"]["message"] == "All components of the initial state `y0` must be finite."
+    cols = {k: np.array([getattr(wt.ReactorConfiguration(), k)]) for k in
+            ("volume", "height", "diameter", "flow_rate", "impeller_speed", "impeller_diameter", "total_carbonate",
+             "temperature", "enable_thermal_stratification", "alkalinity")}
+    par = wt.params.derive_constants(cols, 4)[:, 0]
+    bc = np.array([getattr(wt.BoundaryConditions(), k) for k in wt.params.BOUNDARY_FIELDS])
+    for bad in (np.nan, np.inf, -np.inf):
+        y0 = np.concatenate([[7.0, bad, 7.0, 7.0], np.full(4, 2.0), np.full(4, 20.0)])
+        y, t, der, status = oracle.step(4, par, bc, 1.0, y0, 1.0)
+        assert status == oracle.ST_NONFINITE and t == 1.0 == nf["nan"]["time_after"]
+        assert np.array_equal(y, y0, equal_nan=True)
