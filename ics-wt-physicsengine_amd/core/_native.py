@@ -84,6 +84,10 @@ def lib():
     L.wt_ensemble_get_state.argtypes = [vp, dp, dp, dp, dp, dp]
     L.wt_ensemble_get_derived.argtypes = [vp, dp, dp, dp]
     L.wt_ensemble_get_status.argtypes = [vp, u32p]
+    L.wt_ensemble_get_bad_temperature.argtypes = [vp, dp]
+    L.wt_ensemble_get_bad_temperature.restype = C.c_int
+    L.wt_ensemble_queue_error.argtypes = [vp, C.POINTER(C.c_int)]
+    L.wt_ensemble_queue_error.restype = C.c_int
     L.wt_ensemble_clear_status.argtypes = [vp]
     L.wt_ensemble_get_stats.argtypes = [vp, C.POINTER(SolverStats)]
     L.wt_ensemble_rhs.argtypes = [vp, dp, dp, dp, dp, dp, dp, u32p]

@@ -33,6 +33,7 @@ _T_RANGE_TEXT = (
     "  2. Numerical instability in ODE integration (reduce tolerances)\n"
     "  3. System requires pressurized/supercooled water model")
 _SOLVER_FAILED_TEXT = "ODE solver failed: Required step size is less than spacing between numbers."
+_NONFINITE_TEXT = "All components of the initial state `y0` must be finite."   # scipy base.py:19-20, out of reactor.py:476
 
 
 # --------------------------------------------------------------------------- dataclasses
@@ -329,6 +330,13 @@ class ReactorEnsemble:
         _native.check(_native.lib().wt_ensemble_get_status(self._h, st.ctypes.data_as(C.POINTER(C.c_uint32))))
         return st
 
+    def bad_temperature(self) -> np.ndarray:
+        """(N,) the temperature the reference's ValueError names (thermodynamics.py:151) for reactors whose
+        status carries T_RANGE / T_RANGE_POST; undefined for the others."""
+        v = np.zeros(self.n_reactors)
+        _native.check(_native.lib().wt_ensemble_get_bad_temperature(self._h, _native.dptr(v)))
+        return v
+
     def clear_status(self) -> None:
         _native.check(_native.lib().wt_ensemble_clear_status(self._h))
 
@@ -519,6 +527,7 @@ class IntegratedCSTR:
         config.validate()
         self.config = config
         self._ens = ReactorEnsemble([config], device=device, validate=False)
+        self._ens.set_step_limit(0)      # scipy's solve_ivp has no attempt limit (ReactorEnsemble keeps a guard)
         n = config.n_zones
         c = self._ens.constants[:, 0]
         self.transport = SimpleNamespace(
@@ -556,8 +565,10 @@ class IntegratedCSTR:
                       np.asarray(s.temperature, dtype=np.float64)[None, :], np.array([s.time], dtype=np.float64))
         es = ens.step(dt, boundary, n_steps=1)
         flags = int(es.status[0])
+        if flags & ST_NONFINITE and float(es.time[0]) == float(s.time):
+            raise ValueError(_NONFINITE_TEXT)         # solve_ivp refused y0: self.state untouched
         if flags & ST_T_RANGE:
-            raise ValueError(_T_RANGE_TEXT.format(value="<zone value>"))
+            raise ValueError(_T_RANGE_TEXT.format(value=np.float64(ens.bad_temperature()[0])))
         if flags & ST_STEP_LIMIT:
             logger.warning("ODE solver stopped: internal step-attempt limit reached (see set_step_limit)")
         elif flags & ST_SOLVER_FAILED:
@@ -569,7 +580,7 @@ class IntegratedCSTR:
         s.H_concentration = es.H_concentration[0].copy()
         s.density = es.density[0].copy()
         if flags & ST_T_RANGE_POST:
-            raise ValueError(_T_RANGE_TEXT.format(value="<zone value>"))
+            raise ValueError(_T_RANGE_TEXT.format(value=np.float64(ens.bad_temperature()[0])))
         s.chlorine_decay_rate = es.chlorine_decay_rate[0].copy()
         if flags & ST_CLAMP_PH:
             logger.error("pH out of bounds: clipped to [0, 14]")

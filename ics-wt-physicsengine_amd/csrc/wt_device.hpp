@@ -6,7 +6,11 @@
 // (state, Radau iterates, Jacobian bands, tridiagonal factors) lives in that
 // segment's registers; the 1-D inter-zone stencil, the tridiagonal solves
 // (parallel cyclic reduction) and the RMS norms are DPP / wavefront shuffles.
-// HBM is touched once per launch: state in, state + derived out.
+// HBM is touched once per work item (a wavefront's reactors advanced by a few outer steps): state in,
+// state + derived out.  Work items come from a device-side queue, so one launch advances the whole
+// ensemble by any number of outer steps and no wavefront waits for a launch boundary; the sensor
+// suite and the PLC register image / command path of an outer step run on the same wavefront right
+// behind it (wt_sensors.hpp, wt_plc.hpp).
 //
 // What is computed is the reference's IntegratedCSTR.step():
 //   RHS            reactor.py:272-448 (+ thermodynamics.py:160-193,
@@ -30,6 +34,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "wt_sensors.hpp"
 
 namespace wt {
 
@@ -79,27 +84,31 @@ constexpr double INV_TREF = 0x1.bf1da5ca77e69p-9;  // 1/293.15
 
 struct StepArgs {
     int64_t N;        // reactors in the ensemble (row stride of par / bc)
-    int64_t r0, r1;   // this launch advances reactors [r0, r1)
+    int64_t r0, r1;   // stream schedule: this launch advances reactors [r0, r1); queue schedule: [0, N)
     int n;            // zones per reactor
     int R;            // reactors per wavefront = 64 / n
     const double *par; // [WT_NP][N]
-    const double *bc;  // [WT_NB][N]
+    double *bc;        // [WT_NB][N]  (rows 0, 4, 6 are rewritten by the command path when plant I/O is on)
     double *pH, *Cl, *T; // [N][n]
     double *time, *flow; // [N]
     double *dH, *dRho, *dK; // derived [N][n]
     uint32_t *status;    // [N]
     int32_t *stats;      // [N][5] or nullptr
-    int64_t *wave_diag;  // [n_waves][8] or nullptr: trips, Newton trips, shader clocks, wall clock (100 MHz),
-                         //                          factorize / num_jac / deferred-f block executions, spare
+    int64_t *wave_diag;  // [n_groups][WT_DIAG_SLOTS] or nullptr, accumulated over the work items of a launch:
+                         //   trips, Newton trips, shader clocks, wall clock (100 MHz), factorize / num_jac / deferred-f block executions, items
+    double *bad_T;       // [N] the temperature the reference's ValueError names (thermodynamics.py:151)
     double dt;
-    int n_steps;
-    int sync_outer;   // 1: the reactors of a wavefront start every outer step together
+    int n_steps;      // outer steps this launch advances every reactor by
+    int first_step;   // index of this launch's first step within the wt_ensemble_step call (PLC scan phase)
+    int call_steps;   // outer steps of the whole wt_ensemble_step call
     int step_limit;   // give up an outer step after this many step attempts (0 = never, as the reference)
-    // optional taps for the sensor suite (wt_sensors.hpp): what the sensors look at after every outer step
-    float *taps;         // [n_steps][7][N]: pH0, pHN, Cl0, ClN, T0, TN, flow  (nullptr = off)
-    int32_t *tap_count;  // [N] outer steps completed in this launch
-    double *tap_time;    // [N] ReactorState.time of the last tap
+    // Work queue (nullptr: stream schedule -- workgroup b advances the wavefront-group r0 / R + b by n_steps).
+    // q_ctrl: Q_AVAIL, Q_HEAD, Q_TAIL, Q_ERROR; q_slots[q_cap]: (ticket + 1) << 32 | group; q_next[group]: next step.
+    int32_t *q_ctrl; unsigned long long *q_slots; int32_t *q_next;
+    int q_cap, item_steps, n_groups;
+    wts::SuiteArgs sens; // fused sensor suite + plant I/O (sens.on == 0: none)
 };
+enum { Q_AVAIL = 0, Q_HEAD = 1, Q_TAIL = 2, Q_ERROR = 3, Q_WORDS = 16 };
 
 // ---------------------------------------------------------------- lane geometry and cross-lane moves
 struct Lane {
@@ -208,11 +217,12 @@ __device__ __forceinline__ double powi6(double x, int k)
 struct RK {
     // chemistry.py:116-132 constants (frozen at configuration temperature)
     double Kw, Ka1, Ka1Ka2, KaH, cbeta;
-    // transport / spatial: Richardson test  g*drho*dz > Ri_crit * rho_avg * u^2
-    double Kex, gdz, rcu2, supp;
+    // transport / spatial: Richardson number (g drho dz) / (rho_avg u^2) against Ri_crit (spatial.py:262-277,293)
+    double Kex, dz, u2, ricrit, supp;
     int strat_mode; // 0: stratification off, 1: Richardson test, 2: u<=1e-6 (Ri=+inf)
     // boundary-derived (reactor.py:336,349-368,385-395,426-443)
     double Qv, H_in, Cl_in, T_in, acid_dH, cl_dose, UAr, T_amb;
+    double flowsum;   // inlet + acid + chlorine flow: ReactorState.flow_rate (reactor.py:497-501)
     bool has_acid, has_cl, has_heat;
     // the same, pre-masked for this lane's zone so the RHS needs no per-term selects:
     // inlet / dosing terms act on zone 0 only, the outlet sink on zone n-1 only
@@ -224,17 +234,25 @@ struct RK {
     double UAr_on;    // heat-loss coefficient (0 when off)
 };
 
-__device__ __forceinline__ void load_reactor(const double *par, const double *bc, int64_t N, int64_t r, int n, RK &k)
+// cmd != nullptr: boundary rows 0 / 4 / 6 (inlet, acid, chlorine flow) as the command path has just set them
+__device__ __forceinline__ void load_reactor(const double *par, const double *bc, int64_t N, int64_t r, int n, RK &k,
+                                             const double *cmd = nullptr, int cmd_stride = 0)
 {
     auto P = [&](int row) { return par[(int64_t)row * N + r]; };
-    auto B = [&](int row) { return bc[(int64_t)row * N + r]; };
+    auto B = [&](int row) {
+        if (cmd && row == 0) return cmd[0 * cmd_stride];
+        if (cmd && row == 4) return cmd[1 * cmd_stride];
+        if (cmd && row == 6) return cmd[2 * cmd_stride];
+        return bc[(int64_t)row * N + r];
+    };
     const double V = P(0), height = P(1), diam = P(2);
     k.Kw = P(3); k.Ka1 = P(4); k.Ka1Ka2 = P(4) * P(5); k.KaH = P(6);
     k.cbeta = 2.303 * P(7);                    // chemistry.py:431-433
     k.Kex = P(8);
     const double u = P(9);
-    k.gdz = 9.81 * (height / n);                // spatial.py:119,268
-    k.rcu2 = P(11) * (u * u);                   // Ri_crit * u^2
+    k.dz = height / n;                          // spatial.py:119
+    k.u2 = u * u;                               // velocity_scale ** 2
+    k.ricrit = P(11);
     k.supp = P(12);
     k.strat_mode = (P(10) != 0.0) ? ((u > 1e-6) ? 1 : 2) : 0; // reactor.py:310, spatial.py:270-275
     const double Q_in = B(0);
@@ -252,6 +270,7 @@ __device__ __forceinline__ void load_reactor(const double *par, const double *bc
     const double A_tot = PI * diam * height + 2 * PI * (rr * rr);  // reactor.py:429-431
     k.UAr = (B(9) * A_tot) / (998.2 * 4184 * (V / 1000));          // reactor.py:433-443
     k.T_amb = B(8);
+    k.flowsum = B(0) + B(4) + B(6);
 }
 
 __device__ __forceinline__ void mask_reactor_for_lane(const Lane &L, RK &k)
@@ -268,13 +287,13 @@ __device__ __forceinline__ void mask_reactor_for_lane(const Lane &L, RK &k)
 // estimate) they would occupy 38 VGPRs of a register file that is already oversubscribed, so they are parked
 // in LDS and fetched at the top of every RHS block: 14 per-reactor words (one copy per reactor, broadcast to
 // its lanes) and 5 per-lane ones.
-constexpr int RK_UNI = 14, RK_LANE = 5, RK_MAXR = 32;   // up to 32 reactors per wavefront (n = 2)
+constexpr int RK_UNI = 16, RK_LANE = 5, RK_MAXR = 32;   // up to 32 reactors per wavefront (n = 2)
 struct RKStore { double *uni; double *lane; };          // uni[c * RK_MAXR], lane[c * 64]: already offset for this lane
 
 __device__ __forceinline__ void park_reactor(const RKStore &st, const RK &k)
 {
-    const double u[RK_UNI] = {k.Kw, k.Ka1, k.Ka1Ka2, k.KaH, k.cbeta, k.gdz, k.rcu2, k.supp, k.H_in, k.Cl_in, k.T_in, k.T_amb, k.UAr_on,
-                              (double)k.strat_mode};
+    const double u[RK_UNI] = {k.Kw, k.Ka1, k.Ka1Ka2, k.KaH, k.cbeta, k.dz, k.u2, k.supp, k.H_in, k.Cl_in, k.T_in, k.T_amb, k.UAr_on,
+                              (double)k.strat_mode, k.ricrit, k.flowsum};
     const double l[RK_LANE] = {k.Kex_hi, k.Qv_in, k.Qv_out, k.acid0, k.dose0};
 #pragma unroll
     for (int c = 0; c < RK_UNI; ++c) st.uni[c * RK_MAXR] = u[c];     // every lane of the reactor stores the same value
@@ -286,9 +305,9 @@ __device__ __forceinline__ RK fetch_reactor(const RKStore &st)
 {
     RK k;
     k.Kw = st.uni[0 * RK_MAXR]; k.Ka1 = st.uni[1 * RK_MAXR]; k.Ka1Ka2 = st.uni[2 * RK_MAXR]; k.KaH = st.uni[3 * RK_MAXR];
-    k.cbeta = st.uni[4 * RK_MAXR]; k.gdz = st.uni[5 * RK_MAXR]; k.rcu2 = st.uni[6 * RK_MAXR]; k.supp = st.uni[7 * RK_MAXR];
+    k.cbeta = st.uni[4 * RK_MAXR]; k.dz = st.uni[5 * RK_MAXR]; k.u2 = st.uni[6 * RK_MAXR]; k.supp = st.uni[7 * RK_MAXR];
     k.H_in = st.uni[8 * RK_MAXR]; k.Cl_in = st.uni[9 * RK_MAXR]; k.T_in = st.uni[10 * RK_MAXR]; k.T_amb = st.uni[11 * RK_MAXR];
-    k.UAr_on = st.uni[12 * RK_MAXR]; k.strat_mode = (int)st.uni[13 * RK_MAXR];
+    k.UAr_on = st.uni[12 * RK_MAXR]; k.strat_mode = (int)st.uni[13 * RK_MAXR]; k.ricrit = st.uni[14 * RK_MAXR];
     k.Kex_hi = st.lane[0 * 64]; k.Qv_in = st.lane[1 * 64]; k.Qv_out = st.lane[2 * 64]; k.acid0 = st.lane[3 * 64]; k.dose0 = st.lane[4 * 64];
     return k;
 }
@@ -297,30 +316,39 @@ __device__ __forceinline__ RK fetch_reactor(const RKStore &st)
 struct PropPH { double H, iw, phi; bool bpos; }; // iw = 1/(beta*ln10)
 struct PropT { double kT, rho; bool bad; };
 
+// The RHS is inlined at several places of the solver (stage points, single points, the deferred f(y_new),
+// the finite-difference passes) and the same state must give the same bits at each of them -- f(y0) of an outer
+// step may come from any of them depending on the schedule.  So nothing here is left to the compiler's choice of
+// which products to fuse: contraction is off and every fused multiply-add is spelled out.
+
 // H = 10^-pH, buffering capacity beta (chemistry.py:400-437), HOCl/OCl- decay
 // factor (chemistry.py:483-523).
 __device__ __forceinline__ PropPH prop_pH(const RK &k, double pH)
 {
+#pragma clang fp contract(off)
     PropPH p;
     const double H = exp10(-pH);
-    const double beta_w = 2.303 * (H + k.Kw * rcp(H));
+    const double beta_w = 2.303 * __builtin_fma(k.Kw, rcp(H), H);
     const double H2 = H * H;
-    const double D = H2 + k.Ka1 * H + k.Ka1Ka2;
+    const double D = __builtin_fma(k.Ka1, H, H2) + k.Ka1Ka2;
     const double iD = rcp(D);
     const double a0 = H2 * iD, a1 = (k.Ka1 * H) * iD, a2 = k.Ka1Ka2 * iD;
-    const double beta = beta_w + k.cbeta * (a0 * a1 + 4 * a1 * a2 + a0 * a2);
+    const double mix = __builtin_fma(a0, a2, __builtin_fma(4 * a1, a2, a0 * a1));
+    const double beta = __builtin_fma(k.cbeta, mix, beta_w);
     p.bpos = beta > 0;                           // reactor.py:358,367,375 guards: no pH change unless beta > 0
     p.iw = p.bpos ? rcp(beta * rc::LN10) : 0.0;
     const double iHK = rcp(H + k.KaH);
-    p.phi = H * iHK + (k.KaH * iHK) * 0.02;
+    p.phi = __builtin_fma(k.KaH * iHK, 0.02, H * iHK);
     p.H = H;
     return p;
 }
 
 // Arrhenius decay rate (thermodynamics.py:160-193) with its [0,100] C check
-// (:146-157) and water density (spatial.py:177-189).
+// (:146-157) and water density (spatial.py:177-189).  The density feeds the stratification switch, so it
+// is formed with the reference's roundings: products and sums separately, never fused.
 __device__ __forceinline__ PropT prop_T(double T)
 {
+#pragma clang fp contract(off)
     PropT p;
     p.bad = (T < 0.0) || (T > 100.0);
     const double ex = rc::K_ARR * (rcp(T + 273.15) - rc::INV_TREF);
@@ -340,14 +368,20 @@ template <bool ROW>
 __device__ __forceinline__ void rhs_rows(const Lane &L, const RK &k, double H, double iw, bool bpos, double kphi,
                                          double rho, double Cl, double T, double f[3])
 {
-    // mixing suppression of the interface above this zone (spatial.py:239-320):
-    // Ri = g drho dz / (rho_avg u^2) > Ri_crit  <=>  g dz drho > Ri_crit u^2 rho_avg
+#pragma clang fp contract(off)
+    // mixing suppression of the interface above this zone (spatial.py:239-320): Ri = (g drho dz) / (rho_avg u^2)
+    // > Ri_crit, in the reference's operation order.  The reciprocal product decides unless it lands within
+    // a few ulp of the threshold; only then is the correctly rounded quotient the reference compares formed.
     const double rho_hi = from_hi<ROW, 1>(L, rho);
     double s = 1.0;
     if (k.strat_mode == 1) {
         const double drho = rho_hi - rho;
         const double ravg = 0.5 * (rho + rho_hi);
-        if (k.gdz * drho > k.rcu2 * ravg) s = k.supp;
+        const double num = (9.81 * drho) * k.dz, den = ravg * k.u2;
+        const double q = num * rcp(den);
+        bool stable = q > k.ricrit;
+        if (fabs(q - k.ricrit) <= 1e-13 * k.ricrit) stable = __ddiv_rn(num, den) > k.ricrit;
+        if (stable) s = k.supp;
     } else if (k.strat_mode == 2) {
         s = k.supp;
     }
@@ -358,18 +392,18 @@ __device__ __forceinline__ void rhs_rows(const Lane &L, const RK &k, double H, d
     const double H_lo = keep_m(L.m_lo[0], from_lo<ROW, 1>(L, H)), H_hi = keep_m(L.m_hi[0], from_hi<ROW, 1>(L, H));
     const double C_lo = keep_m(L.m_lo[0], from_lo<ROW, 1>(L, Cl)), C_hi = keep_m(L.m_hi[0], from_hi<ROW, 1>(L, Cl));
     const double T_lo = keep_m(L.m_lo[0], from_lo<ROW, 1>(L, T)), T_hi = keep_m(L.m_hi[0], from_hi<ROW, 1>(L, T));
-    // K @ x with OpenBLAS' accumulation order: neighbours first, diagonal last.  k_lo / k_hi are
-    // exactly 0 where there is no neighbour, and what was read there is finite (keep_m).
-    const double mixH = (k_lo * H_lo + k_hi * H_hi) + kd * H;
-    const double mixC = (k_lo * C_lo + k_hi * C_hi) + kd * Cl;
-    const double mixT = (k_lo * T_lo + k_hi * T_hi) + kd * T;
+    // K @ x the way OpenBLAS' dgemv accumulates it inside the reference: neighbours first, diagonal last, each
+    // product fused into the running sum.  k_lo / k_hi are exactly 0 where there is no neighbour, and what
+    // was read there is finite (keep_m).
+    const double mixH = __builtin_fma(kd, H, __builtin_fma(k_hi, H_hi, k_lo * H_lo));
+    const double mixC = __builtin_fma(kd, Cl, __builtin_fma(k_hi, C_hi, k_lo * C_lo));
+    const double mixT = __builtin_fma(kd, T, __builtin_fma(k_hi, T_hi, k_lo * T_lo));
 
     // zone-0 dosing and inlet (reactor.py:349-368,388-395,420) through pre-masked coefficients;
     // iw is 0 when the reference's `beta > 0` guard fails
-    const double dpH = -((k.acid0 + k.Qv_in * (k.H_in - H)) + mixH) * iw;            // reactor.py:349-376
-    double dCl = (k.dose0 + k.Qv_in * (k.Cl_in - Cl)) + mixC;                        // reactor.py:385-398
-    dCl -= kphi * Cl;                                                                 // reactor.py:401-411
-    const double dT = (k.Qv_in * (k.T_in - T) + mixT) - k.UAr_on * (T - k.T_amb);    // reactor.py:420-443
+    const double dpH = -(__builtin_fma(k.Qv_in, k.H_in - H, k.acid0) + mixH) * iw;          // reactor.py:349-376
+    const double dCl = __builtin_fma(-kphi, Cl, __builtin_fma(k.Qv_in, k.Cl_in - Cl, k.dose0) + mixC);   // reactor.py:385-411
+    const double dT = __builtin_fma(-k.UAr_on, T - k.T_amb, k.Qv_in * (k.T_in - T) + mixT);  // reactor.py:420-443
     (void)bpos;
     f[SPH] = dpH; f[SCL] = dCl; f[STT] = dT;
 }
@@ -630,12 +664,15 @@ __device__ __forceinline__ double sel3(double x0, double x1, double x2, int idx)
 // out.D[q][r] is the change of this lane's row q when the zone at offset r-1 was perturbed.
 template <bool ROW, int SP>
 __device__ __forceinline__ void fd_species_pass(const Lane &L, const RK &k, const double y[3], const double f[3],
-                                                const ZoneProps &b, double hcol, bool colmask, FdCols &out, bool &bad)
+                                                const ZoneProps &b, double hcol, bool colmask, FdCols &out, bool &bad, double &badval)
 {
     const double ypert = y[SP] + hcol;
     ZoneProps p = b;
     if constexpr (SP == SPH) { const PropPH q = prop_pH(k, ypert); p.H = q.H; p.iw = q.iw; p.phi = q.phi; p.bpos = q.bpos; }
-    if constexpr (SP == STT) { const PropT q = prop_T(ypert); p.kT = q.kT; p.rho = q.rho; bad = bad || (colmask && q.bad); }
+    if constexpr (SP == STT) {
+        const PropT q = prop_T(ypert); p.kT = q.kT; p.rho = q.rho;
+        if (colmask && q.bad && !bad) { bad = true; badval = ypert; }   // the reference raises on this perturbed column
+    }
     const int zm = L.z % 3;
     double Dc[3][3], Sc[3][3];   // [row species][colour], statically indexed
 #pragma unroll
@@ -708,13 +745,13 @@ __device__ __forceinline__ double fd_step(double y, double fac, double ysc)
 // (already divided by the column's h).
 template <bool ROW, int SP>
 __device__ __forceinline__ void num_jac_species(const Lane &L, const RK &k, const double y[3], const double f[3],
-                                                const ZoneProps &b, double &fac, FdCols &cols, bool &bad)
+                                                const ZoneProps &b, double &fac, FdCols &cols, bool &bad, double &badval)
 {
     const double fs = (f[SP] >= 0) ? 1.0 : -1.0;
     const double ysc = fs * fmax(ATOL, fabs(y[SP]));
     double h = fd_step(y[SP], fac, ysc);
     while (h == 0) { fac *= 10; h = fd_step(y[SP], fac, ysc); }    // common.py:327-330
-    fd_species_pass<ROW, SP>(L, k, y, f, b, h, true, cols, bad);
+    fd_species_pass<ROW, SP>(L, k, y, f, b, h, true, cols, bad, badval);
     double maxd, scl;
     fd_col_reduce<ROW, SP>(L, cols, maxd, scl);
     const bool small = maxd < rc::NJ_REJECT * scl;                  // common.py:341
@@ -722,7 +759,7 @@ __device__ __forceinline__ void num_jac_species(const Lane &L, const RK &k, cons
         const double nf = 10 * fac;
         const double hn = fd_step(y[SP], nf, ysc);
         FdCols c2;
-        fd_species_pass<ROW, SP>(L, k, y, f, b, hn, small, c2, bad);
+        fd_species_pass<ROW, SP>(L, k, y, f, b, hn, small, c2, bad, badval);
         double md2, sc2;
         fd_col_reduce<ROW, SP>(L, c2, md2, sc2);
         const bool upd = small && (maxd * sc2 < md2 * scl);         // common.py:354
@@ -751,21 +788,21 @@ __device__ __forceinline__ void num_jac_species(const Lane &L, const RK &k, cons
 
 template <bool ROW>
 __device__ __forceinline__ void num_jac(const Lane &L, const RK &k, const double y[3], const double f[3],
-                                        double fac[3], bool &have_fac, Jac &J, bool &bad)
+                                        double fac[3], bool &have_fac, Jac &J, bool &bad, double &badval)
 {
     if (!have_fac) { fac[0] = fac[1] = fac[2] = rc::NJ_F0; have_fac = true; }
     const PropPH bpp = prop_pH(k, y[SPH]);
     const PropT bpt = prop_T(y[STT]);
     const ZoneProps b = {bpp.H, bpp.iw, bpp.phi, bpt.kT, bpt.rho, bpp.bpos};
     FdCols cols;
-    num_jac_species<ROW, SPH>(L, k, y, f, b, fac[SPH], cols, bad);
+    num_jac_species<ROW, SPH>(L, k, y, f, b, fac[SPH], cols, bad, badval);
 #pragma unroll
     for (int r = 0; r < 3; ++r) J.pp[r] = cols.D[SPH][r];
     J.cp = cols.D[SCL][1];
-    num_jac_species<ROW, SCL>(L, k, y, f, b, fac[SCL], cols, bad);
+    num_jac_species<ROW, SCL>(L, k, y, f, b, fac[SCL], cols, bad, badval);
 #pragma unroll
     for (int r = 0; r < 3; ++r) J.cc[r] = cols.D[SCL][r];
-    num_jac_species<ROW, STT>(L, k, y, f, b, fac[STT], cols, bad);
+    num_jac_species<ROW, STT>(L, k, y, f, b, fac[STT], cols, bad, badval);
 #pragma unroll
     for (int r = 0; r < 3; ++r) { J.tt[r] = cols.D[STT][r]; J.pt[r] = cols.D[SPH][r]; J.ct[r] = cols.D[SCL][r]; }
 }
@@ -811,19 +848,20 @@ struct Flag {
 
 enum Phase : int {
     PH_OUTER_BEGIN = 0, // start an outer step: next trip evaluates f0 = f(y0)            radau.py:303
-    PH_F1,              // trip evaluated f0; next evaluates f(y0 + h0 f0)                  common.py:120-122
+    PH_INIT_STEP,       // f0 known: first half of select_initial_step (no evaluation needed)  common.py:111-119
+    PH_F1,              // next evaluates f(y0 + h0 f0)                                     common.py:120-122
     PH_STEP_BEGIN,      // _step_impl prologue (no evaluation needed)                       radau.py:399-424
     PH_ATTEMPT,         // (re)start an attempt with the current h_abs                      radau.py:426-448
     PH_NEWTON,          // one simplified-Newton iteration per trip (three evaluations)     radau.py:84-134
     PH_ERR_REFINE,      // second error estimate after a rejection (one evaluation)         radau.py:485-487
     PH_FNEW,            // step accepted: evaluate f(y_new), bookkeeping                     radau.py:500-539
-    PH_OUTER_END,       // solve finished or failed: post-step, next outer step or exit     reactor.py:493-507
-    PH_EXIT
+    PH_DONE             // solve finished, failed or raised: wait for the wavefront's other reactors
 };
 
 struct SolverCounters { int nfev, njev, nlu, nsteps, nrej; };
 
-__device__ __forceinline__ bool lane_setup(int64_t r0, int64_t r1, int n, int R, Lane &L, int64_t &r)
+// lane -> (segment, zone) geometry; the same for every work item of a wavefront
+__device__ __forceinline__ void lane_geometry(int n, Lane &L)
 {
     const int lane = threadIdx.x & 63;
     const int seg = lane / n;
@@ -840,445 +878,633 @@ __device__ __forceinline__ bool lane_setup(int64_t r0, int64_t r1, int n, int R,
         asm("" : "+v"(L.m_hi[l]));
     }
     L.segmask = ((n >= 64) ? ~0ull : ((1ull << n) - 1ull)) << L.base;
+}
+
+// rhs_kernel / selftest: one wavefront-group per workgroup
+__device__ __forceinline__ bool lane_setup(int64_t r0, int64_t r1, int n, int R, Lane &L, int64_t &r)
+{
+    lane_geometry(n, L);
+    const int seg = (threadIdx.x & 63) / n;
     r = r0 + (int64_t)blockIdx.x * R + seg;
     return (seg < R) && (r < r1);
 }
 
-template <int LV, bool ROW>
-__global__ __launch_bounds__(64) void step_kernel(const StepArgs a)
+// LDS of one wavefront, ONE array: [reactor constants | history base | factor store, reused between outer steps as StepIO]
+template <int LV> struct LdsMap {
+    static constexpr int RK_DOUBLES = RK_UNI * RK_MAXR + RK_LANE * 64;
+    static constexpr int HIST_DOUBLES = RK_MAXR / 2;                      // RK_MAXR ints
+    static constexpr int F_DOUBLES = FSlots<LV>::LDS_SLOTS * 64;
+    static constexpr int IO_DOUBLES = (int)((sizeof(wts::StepIO) + 7) / 8);
+    static constexpr int TAIL_DOUBLES = F_DOUBLES > IO_DOUBLES ? F_DOUBLES : IO_DOUBLES;
+    static constexpr int TOTAL = RK_DOUBLES + HIST_DOUBLES + TAIL_DOUBLES;
+};
+
+// ---- device-side work queue: FIFO of wavefront-groups that are ready for their next item (wave-uniform calls) ----
+// Tickets 0 .. n_groups-1 are the groups themselves (every group starts ready); ticket n_groups + p is the p-th push.
+// Q_AVAIL counts published, unclaimed entries, so a claimed ticket is always (about to be) written: the only wait
+// is for a pusher that sits between its tail increment and its slot store.
+__device__ __forceinline__ int queue_resolve(const StepArgs &a, int ticket)
 {
-    Lane L; int64_t r;
-    if (!lane_setup(a.r0, a.r1, a.n, a.R, L, r)) return;
-    const int64_t idx = r * a.n + L.z;
-    uint32_t st = a.status[r];
-    // a reactor whose last step raised stays frozen until the host rewrites its state
-    if (st & (ST_T_RANGE | ST_T_RANGE_POST)) { if (a.tap_count && L.z == 0) a.tap_count[r] = 0; return; }
-    __shared__ double lds_rk[RK_UNI * RK_MAXR + RK_LANE * 64];
-    const RKStore ks = {lds_rk + (threadIdx.x & 63) / a.n, lds_rk + RK_UNI * RK_MAXR + (threadIdx.x & 63)};
-    {
-        RK k0; load_reactor(a.par, a.bc, a.N, r, a.n, k0); mask_reactor_for_lane(L, k0);
+    if (ticket < a.n_groups) return ticket;
+    const unsigned long long want = (unsigned long long)(unsigned)(ticket + 1);
+    unsigned long long *slot = a.q_slots + (ticket - a.n_groups) % a.q_cap;
+    for (int spin = 0; spin < (1 << 22); ++spin) {
+        const unsigned long long w = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((w >> 32) == want) return (int)(w & 0xffffffffull);
+        __builtin_amdgcn_s_sleep(2);
+    }
+    __hip_atomic_store(a.q_ctrl + Q_ERROR, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // never seen; the host reports it
+    return -1;
+}
+
+__device__ __forceinline__ void queue_push(const StepArgs &a, int group)
+{
+    const int p = __hip_atomic_fetch_add(a.q_ctrl + Q_TAIL, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long w = ((unsigned long long)(unsigned)(a.n_groups + p + 1) << 32) | (unsigned)group;
+    __hip_atomic_store(a.q_slots + p % a.q_cap, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(a.q_ctrl + Q_AVAIL, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Next group for this worker, or -1 to retire.  own >= 0: the group just advanced still has steps to go -- it goes to
+// the back of the queue if another group is waiting (fair rotation: with more groups than resident wavefronts every
+// group advances at the same rate and nobody idles), otherwise this worker simply carries on with it.
+__device__ __forceinline__ int queue_next(const StepArgs &a, int own)
+{
+    int next = -1;
+    if ((threadIdx.x & 63) == 0) {
+        const int old = __hip_atomic_fetch_add(a.q_ctrl + Q_AVAIL, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old > 0) {
+            const int t = __hip_atomic_fetch_add(a.q_ctrl + Q_HEAD, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (own >= 0) queue_push(a, own);
+            next = queue_resolve(a, t);
+        } else {
+            __hip_atomic_fetch_add(a.q_ctrl + Q_AVAIL, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            next = own;
+        }
+    }
+    return __builtin_amdgcn_readfirstlane(next);
+}
+
+// The argument block has ~80 pointers; held in SGPRs across the solver loop they would crowd out the loop's own
+// scalars (the compiler hoists kernel-argument loads to the top of the kernel and then spills them).  Each section
+// of a work item therefore re-reads what it needs from the kernel-argument segment through a pointer the
+// optimiser cannot see through, which ends the live ranges at the section's end.
+typedef const __attribute__((address_space(4))) StepArgs *ArgPtr;
+__device__ __forceinline__ ArgPtr fresh(ArgPtr p)
+{
+    asm volatile("" : "+s"(p));
+    return p;
+}
+
+// One work item: the reactors of wavefront-group `group` advanced by `cnt` outer steps, starting with step `step0`
+// of this launch.  Reactors of a wavefront start every outer step together (they wait for the slowest of them), so
+// their Jacobians, factorisations and Newton trips coincide, and the end of an outer step is a wave-uniform point
+// where the sensor suite and the PLC scan run.
+template <int LV, bool ROW>
+__device__ __forceinline__ void run_item(ArgPtr pa, const Lane &L, double *lds, int group, int step0, int cnt)
+{
+    using M = LdsMap<LV>;
+    ArgPtr a = fresh(pa);                             // ---- section: load the group
+    const int n_zones = a->n, R = a->R;
+    const int lane = threadIdx.x & 63, seg = lane / n_zones;
+    const int64_t r_first = (int64_t)group * R;
+    const int64_t r_end = a->q_ctrl ? a->N : a->r1;
+    const int64_t r = r_first + seg;
+    const bool present = (seg < R) && (r < r_end);
+    const int64_t idx = r * n_zones + L.z;
+    const double dt = a->dt;
+    const int step_limit = a->step_limit, sens_on = a->sens.on, plc_on = a->sens.plc_on;
+    const bool want_diag = a->wave_diag != nullptr;
+    const RKStore ks = {lds + seg, lds + RK_UNI * RK_MAXR + lane};
+    int *hist0 = reinterpret_cast<int *>(lds + M::RK_DOUBLES);
+    double *lds_factors = lds + M::RK_DOUBLES + M::HIST_DOUBLES;
+    wts::StepIO &io = *reinterpret_cast<wts::StepIO *>(lds_factors);
+
+    // ---- per-reactor state carried from one outer step to the next (segment-uniform scalars replicated in every lane)
+    double y0[3] = {7.0, 1.0, 20.0};                  // state at the start of the outer step
+    double f[3] = {0, 0, 0};                          // f(y0) when f_valid
+    double t_out = 0;                                 // ReactorState.time
+    double dH = 0, dR = 0, dK = 0, badval = 0;
+    double flow_used = 0;                             // ReactorState.flow_rate: the flows of the last step taken
+    uint32_t st = 0;
+    bool frozen = !present, f_valid = false, wrote_k = false, raised = false;
+    int steps_done = 0;
+    SolverCounters last_cnt = {0, 0, 0, 0, 0};
+    long long diag_trips = 0, diag_newton = 0, diag_fact = 0, diag_jac = 0, diag_f3 = 0;
+    const long long clk0 = want_diag ? __builtin_amdgcn_s_memtime() : 0, wall0 = want_diag ? __builtin_amdgcn_s_memrealtime() : 0;
+    if (present) {
+        st = a->status[r];
+        // a reactor whose last step raised stays frozen until the host rewrites its state
+        if (st & (ST_T_RANGE | ST_T_RANGE_POST)) frozen = true;
+        y0[SPH] = a->pH[idx]; y0[SCL] = a->Cl[idx]; y0[STT] = a->T[idx];
+        t_out = a->time[r];
+        RK k0; load_reactor(a->par, a->bc, a->N, r, n_zones, k0); mask_reactor_for_lane(L, k0);
         park_reactor(ks, k0);
+        if (sens_on && L.z == 0) hist0[seg] = a->sens.hist_value ? a->sens.hist_pos[r] : 0;
     }
 
-    // ---- per-reactor state (segment-uniform scalars are replicated in every lane)
-    double y0[3] = {a.pH[idx], a.Cl[idx], a.T[idx]}; // state at the start of the outer step
-    double yc[3], f[3];                               // solver's current y, f(y)
-    double W[3][3];                                   // Newton iterate in transformed variables
-    double aux[3] = {0, 0, 0};                        // y0 + h0 f0 (initial step) / error vector (refinement)
-    double Q[3][3], y_old[3] = {0, 0, 0};             // dense output of the last accepted step
-    Jac J;
-    __shared__ double lds_factors[FSlots<LV>::LDS_SLOTS * 64];
-    FStore<LV> F;
-    F.base = lds_factors + (threadIdx.x & 63);
-    uint32_t fl = 1u << 4;                            // current_jac = true
-    Flag have_fac{fl, 1u << 0}, have_old{fl, 1u << 1}, have_old_l{fl, 1u << 2}, have_sol{fl, 1u << 3}, current_jac{fl, 1u << 4},
-         have_lu{fl, 1u << 5}, rejected{fl, 1u << 6}, keep_h{fl, 1u << 7}, have_norm_old{fl, 1u << 8}, have_rate{fl, 1u << 9},
-         bad{fl, 1u << 10}, failed{fl, 1u << 11}, f_valid{fl, 1u << 12}, need_jac{fl, 1u << 13}, wrote_k{fl, 1u << 14},
-         advanced{fl, 1u << 15}, limit_hit{fl, 1u << 16}, pend_f{fl, 1u << 17}, jac_after_fnew{fl, 1u << 18};
-    double fac[3] = {0, 0, 0};
-    double t_out = a.time[r];                         // ReactorState.time
-    double t = 0, t_bound = 0, max_step = 0;
-    double h = 0, t_new = 0, h_abs = 0, h_abs_l = 0, min_step = 0;
-    double h_abs_old = 0, err_old = 0, h_abs_old_l = 0, err_old_l = 0;
-    double sol_t_old = 0, sol_h = 1;
-    int kk = 0, n_iter = 0; double dW_norm_old = 0, rate = 0;
-    double error_norm = 0, safety = 0;
-    double d0 = 0, d1 = 0, h0 = 0;                    // select_initial_step
-    double dH = 0, dR = 0, dK = 0;
-    SolverCounters cnt = {0, 0, 0, 0, 0};
-    int steps_left = a.n_steps;
-    int attempts = 0;   // guard against unbounded solves (sliding along a discontinuity): see limit_hit
-    // pend_f: f(yc) of the last accepted step has not been evaluated yet
-    // jac_after_fnew: that step also asked for a fresh Jacobian (radau.py:500,512)
-    int phase = PH_OUTER_BEGIN;
-    long long diag_trips = 0, diag_newton = 0, diag_fact = 0, diag_jac = 0, diag_f3 = 0;
-#ifdef WT_STAMPS  // diagnostic build only: shader-clock shares of the loop's sections (never in the product .so)
-    long long sec[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long tprev = __builtin_amdgcn_s_memtime();
-#define WT_STAMP(i) do { const long long tn_ = __builtin_amdgcn_s_memtime(); sec[i] += tn_ - tprev; tprev = tn_; } while (0)
-#else
-#define WT_STAMP(i) do { } while (0)
-#endif
+    for (int k = 0; k < cnt; ++k) {
+        bool stepped = false;
+        if (!frozen) {
+          // scipy refuses a non-finite initial state: ValueError out of step(), self.state untouched (base.py:19-20)
+          if (seg_any(L, !(isfinite(y0[0]) && isfinite(y0[1]) && isfinite(y0[2])))) { st |= ST_NONFINITE; frozen = true; }
+          else {
+            // ================= one IntegratedCSTR.step(): a fresh scipy solver object (reactor.py:476)
+            double yc[3], W[3][3];                    // solver's current y; Newton iterate in transformed variables
+            double aux[3] = {0, 0, 0};                // y0 + h0 f0 (initial step) / error vector (refinement)
+            double Q[3][3], y_old[3] = {0, 0, 0};     // dense output of the last accepted step
+            Jac J;
+            FStore<LV> F;
+            F.base = lds_factors + lane;
+            uint32_t fl = 1u << 4;                    // current_jac = true
+            Flag have_fac{fl, 1u << 0}, have_old{fl, 1u << 1}, have_old_l{fl, 1u << 2}, have_sol{fl, 1u << 3}, current_jac{fl, 1u << 4},
+                 have_lu{fl, 1u << 5}, rejected{fl, 1u << 6}, keep_h{fl, 1u << 7}, have_norm_old{fl, 1u << 8}, have_rate{fl, 1u << 9},
+                 bad{fl, 1u << 10}, failed{fl, 1u << 11}, fv{fl, 1u << 12}, need_jac{fl, 1u << 13},
+                 limit_hit{fl, 1u << 16}, pend_f{fl, 1u << 17}, jac_after_fnew{fl, 1u << 18};
+            fv = f_valid;
+            double fac[3] = {0, 0, 0};
+            double t = t_out, t_bound = t_out + dt, max_step = fmin(dt, 10.0);
+            double h = 0, t_new = 0, h_abs = 0, h_abs_l = 0, min_step = 0;
+            double h_abs_old = 0, err_old = 0, h_abs_old_l = 0, err_old_l = 0;
+            double sol_t_old = 0, sol_h = 1;
+            int kk = 0, n_iter = 0; double dW_norm_old = 0, rate = 0;
+            double error_norm = 0, safety = 0;
+            double d0 = 0, d1 = 0, h0 = 0;            // select_initial_step
+            SolverCounters cnt_s = {0, 0, 0, 0, 0};
+            int attempts = 0;   // guard against unbounded solves (sliding along a discontinuity): see limit_hit
+            int badstage = 0;   // which evaluation of the trip raised: 0 deferred f(y_new), 1..3 stage / single point
+            // pend_f: f(yc) of the last accepted step has not been evaluated yet
+            // jac_after_fnew: that step also asked for a fresh Jacobian (radau.py:500,512)
+            int phase = PH_OUTER_BEGIN;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) { yc[q] = y0[q]; W[0][q] = W[1][q] = W[2][q] = 0.0; Q[q][0] = Q[q][1] = Q[q][2] = 0.0; }
 
-    // select_initial_step (common.py:68-134), order 3, up to the probe point y0 + h0 f0
-    auto initial_step_first_half = [&]() {
-        double sc[3];
+            // select_initial_step (common.py:68-134), order 3, up to the probe point y0 + h0 f0
+            auto initial_step_first_half = [&]() {
+                double sc[3];
 #pragma unroll
-        for (int q = 0; q < 3; ++q) sc[q] = ATOL + fabs(yc[q]) * RTOL;
-        d0 = rms3<ROW>(L, yc, sc); d1 = rms3<ROW>(L, f, sc);
-        h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 * rcp(d1);
-        h0 = fmin(h0, fabs(t_bound - t));
+                for (int q = 0; q < 3; ++q) sc[q] = ATOL + fabs(yc[q]) * RTOL;
+                d0 = rms3<ROW>(L, yc, sc); d1 = rms3<ROW>(L, f, sc);
+                h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 * rcp(d1);
+                h0 = fmin(h0, fabs(t_bound - t));
 #pragma unroll
-        for (int q = 0; q < 3; ++q) aux[q] = yc[q] + h0 * f[q];
-    };
-    // error_norm > 1: radau.py:489-496
-    auto reject_step = [&]() {
-        const double fct = predict_factor(h_abs_l, have_old_l, h_abs_old_l, error_norm, err_old_l);
-        h_abs_l *= fmax(MIN_FACTOR, safety * fct);
-        have_lu = false; rejected = true; cnt.nrej++;
-        phase = PH_ATTEMPT;
-    };
-    // step accepted: radau.py:500-539.  scipy evaluates f(y_new) right here; the value is first
-    // needed by the next error estimate, so unless a Jacobian refresh or the end of the outer
-    // step needs it at once, it is evaluated together with the next Newton trip (pend_f).
-    auto accept_step = [&]() {
-        const bool recompute_jac = (n_iter > 2) && have_rate && (rate > 1e-3);
-        double fct = predict_factor(h_abs_l, have_old_l, h_abs_old_l, error_norm, err_old_l);
-        fct = fmin(MAX_FACTOR, safety * fct);
-        if (!recompute_jac && fct < 1.2) fct = 1.0; else have_lu = false;
-        h_abs_old = h_abs;            // sic radau.py:520: the solver-level value
-        err_old = error_norm;
-        have_old = true;
-        h_abs = h_abs_l * fct;
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            const double z0 = rc::T00 * W[0][q] + rc::T01 * W[1][q] + rc::T02 * W[2][q];
-            const double z1 = rc::T10 * W[0][q] + rc::T11 * W[1][q] + rc::T12 * W[2][q];
-            const double z2 = W[0][q] + W[1][q];
-            y_old[q] = yc[q];
-            Q[q][0] = z0 * rc::P00 + z1 * rc::P10 + z2 * rc::P20;  // Q = Z^T P  radau.py:541-543
-            Q[q][1] = z0 * rc::P01 + z1 * rc::P11 + z2 * rc::P21;
-            Q[q][2] = z0 * rc::P02 + z1 * rc::P12 + z2 * rc::P22;
-            yc[q] = yc[q] + z2;
-        }
-        sol_t_old = t; sol_h = t_new - t; have_sol = true;
-        t = t_new;
-        cnt.nsteps++; cnt.nfev++;     // f(y_new) counted where scipy calls it
-        pend_f = true; f_valid = false;
-        current_jac = recompute_jac;
-        const bool more = (t - t_bound) < 0;
-        if (recompute_jac || !more) { jac_after_fnew = recompute_jac; phase = PH_FNEW; }
-        else phase = PH_STEP_BEGIN;
-    };
-    const long long clk0 = a.wave_diag ? __builtin_amdgcn_s_memtime() : 0, wall0 = a.wave_diag ? __builtin_amdgcn_s_memrealtime() : 0;
-
-    while (true) {
-        // ================= trips that need no RHS evaluation (run first so the lane can join this trip's evaluation)
-        // Optional rendez-vous: reactors that finished their outer step wait until every reactor of the
-        // wavefront has, so Jacobians, factorisations and Newton trips of the next step coincide again.
-        const bool hold_outer = a.sync_outer && (__ballot(phase != PH_OUTER_END && phase != PH_EXIT) != 0ull);
-        if (phase == PH_OUTER_END && !hold_outer) {
-            if (bad) {
-                st |= ST_T_RANGE;                      // the reference raised: self.state untouched
-                phase = PH_EXIT;
-            } else {
-                if (failed) st |= ST_SOLVER_FAILED;    // reactor.py:486-487; state <- last accepted y
-                if (limit_hit) st |= ST_STEP_LIMIT;
-#pragma unroll
-                for (int q = 0; q < 3; ++q) y0[q] = yc[q];
-                advanced = true;
-                t_out = t_out + a.dt;                  // reactor.py:496
-                // _update_derived_state reactor.py:511-524 (before the clamp)
-                dH = exp10(-y0[SPH]);
-                const PropT pt = prop_T(y0[STT]);
-                dR = pt.rho;
-                bool clamped = false;
-                if (seg_any(L, pt.bad)) { st |= ST_T_RANGE_POST; phase = PH_EXIT; }
-                else {
-                    dK = pt.kT; wrote_k = true;
-                    // _enforce_physical_bounds reactor.py:526-541
-                    if (seg_any(L, y0[SPH] < 0 || y0[SPH] > 14)) { st |= ST_CLAMP_PH; y0[SPH] = fmin(fmax(y0[SPH], 0.0), 14.0); clamped = true; }
-                    if (seg_any(L, y0[SCL] < 0)) { st |= ST_CLAMP_CL; y0[SCL] = fmax(y0[SCL], 0.0); clamped = true; }
-                    if (seg_any(L, y0[STT] < 0 || y0[STT] > 100)) { st |= ST_CLAMP_T; y0[STT] = fmin(fmax(y0[STT], 0.0), 100.0); clamped = true; }
-                    if (seg_any(L, !(isfinite(y0[0]) && isfinite(y0[1]) && isfinite(y0[2])))) st |= ST_NONFINITE;
-                    // f(y) of the last accepted point is f0 of the next outer step when nothing touched y
-                    f_valid = f_valid && !clamped && !failed;
-                    if (a.taps) {   // what read_all_sensors sees after this step (__main__.py:403-410)
-                        float *tp = a.taps + ((int64_t)(a.n_steps - steps_left) * 7) * a.N + r;
-                        if (!L.has_lo) {
-                            tp[0 * a.N] = (float)y0[SPH]; tp[2 * a.N] = (float)y0[SCL]; tp[4 * a.N] = (float)y0[STT];
-                            tp[6 * a.N] = (float)(a.bc[0 * a.N + r] + a.bc[4 * a.N + r] + a.bc[6 * a.N + r]);
-                            a.tap_time[r] = t_out;
-                        }
-                        if (!L.has_hi) { tp[1 * a.N] = (float)y0[SPH]; tp[3 * a.N] = (float)y0[SCL]; tp[5 * a.N] = (float)y0[STT]; }
-                    }
-                    steps_left--;
-                    phase = (steps_left > 0) ? PH_OUTER_BEGIN : PH_EXIT;
-                }
-            }
-        }
-        if (__ballot(phase != PH_EXIT) == 0ull) break;
-        WT_STAMP(0);   // outer-step bookkeeping
-
-        if (phase == PH_OUTER_BEGIN) {
-            // a fresh scipy solver object per outer step (reactor.py:476)
-            t = t_out; t_bound = t_out + a.dt; max_step = fmin(a.dt, 10.0);
-#pragma unroll
-            for (int q = 0; q < 3; ++q) yc[q] = y0[q];
-            have_fac = false; have_sol = false; have_old = false; have_lu = false; current_jac = true;
-            failed = false; pend_f = false; attempts = 0; limit_hit = false;
-            cnt = {0, 0, 0, 0, 0};
-            if (f_valid) {
-                // f(y0) is already in f (last evaluation of the previous outer step, same y, same
-                // boundary): count it as scipy does and go straight to the initial-step probe
-                cnt.nfev++;
-                initial_step_first_half();
-                phase = PH_F1;
-            }
-        }
-        if (phase == PH_STEP_BEGIN) {
-            min_step = 10 * fabs(ulp_above(t));                      // radau.py:408
-            if (h_abs > max_step) { h_abs_l = max_step; have_old_l = false; }
-            else if (h_abs < min_step) { h_abs_l = min_step; have_old_l = false; }
-            else { h_abs_l = h_abs; have_old_l = have_old; h_abs_old_l = h_abs_old; err_old_l = err_old; }
-            rejected = false; keep_h = false;
-            phase = PH_ATTEMPT;
-        }
-        if (phase == PH_ATTEMPT) {
-            if (!keep_h) {
-                if (a.step_limit > 0 && attempts >= a.step_limit) { failed = true; limit_hit = true; phase = PH_OUTER_END; }
-                else if (h_abs_l < min_step) { failed = true; phase = PH_OUTER_END; }  // radau.py:427-428
-                else {
-                    attempts++;
-                    h = h_abs_l;
-                    t_new = t + h;
-                    if (t_new - t_bound > 0) t_new = t_bound;
-                    h = t_new - t;
-                    h_abs_l = fabs(h);
-                }
-            }
-            if (phase == PH_ATTEMPT) {
-                keep_h = false;
-                // initial guess Z0 (radau.py:445-448,557-572) and W = TI Z0 (radau.py:88)
-                double Z0[3][3];
-                if (!have_sol) {
-#pragma unroll
-                    for (int s = 0; s < 3; ++s)
-#pragma unroll
-                        for (int q = 0; q < 3; ++q) Z0[s][q] = 0.0;
-                } else {
-                    const double isol = rcp(sol_h);
-                    const double cs[3] = {rc::C0, rc::C1, 1.0};
-#pragma unroll
-                    for (int s = 0; s < 3; ++s) {
-                        const double x = ((t + h * cs[s]) - sol_t_old) * isol;
-                        const double p1 = x * x, p2 = p1 * x;
-#pragma unroll
-                        for (int q = 0; q < 3; ++q)
-                            Z0[s][q] = ((Q[q][0] * x + Q[q][1] * p1 + Q[q][2] * p2) + y_old[q]) - yc[q];
-                    }
-                }
-#pragma unroll
-                for (int q = 0; q < 3; ++q) {
-                    W[0][q] = rc::TI00 * Z0[0][q] + rc::TI01 * Z0[1][q] + rc::TI02 * Z0[2][q];
-                    W[1][q] = rc::TI10 * Z0[0][q] + rc::TI11 * Z0[1][q] + rc::TI12 * Z0[2][q];
-                    W[2][q] = rc::TI20 * Z0[0][q] + rc::TI21 * Z0[1][q] + rc::TI22 * Z0[2][q];
-                }
-                kk = 0; have_norm_old = false; have_rate = false; rate = 0.0;
-                phase = PH_NEWTON;
-            }
-        }
-        WT_STAMP(1);   // step / attempt prologues
-        if (__ballot(phase == PH_NEWTON && !have_lu) != 0ull) diag_fact++;
-        if (phase == PH_NEWTON && !have_lu) {
-            factorize<ROW, LV>(L, J, h, F); have_lu = true; cnt.nlu += 2;      // radau.py:454-456
-        }
-
-
-        WT_STAMP(2);   // factorisation
-        // ================= this trip's evaluation points
-        const bool newton = (phase == PH_NEWTON);
-        diag_trips++; if (__ballot(newton) != 0ull) diag_newton++;
-        const bool eval0 = (phase == PH_OUTER_BEGIN || phase == PH_F1 || phase == PH_ERR_REFINE || phase == PH_FNEW || newton);
-        // f(y) of a just-accepted step rides along with the next attempt's first Newton trip
-        const bool eval3 = newton && pend_f;
-        double ye[3][3], Fe[3][3];
-        // Z = T W (radau.py:124): Z[2] = W0 + W1
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            const double z0 = rc::T00 * W[0][q] + rc::T01 * W[1][q] + rc::T02 * W[2][q];
-            const double z1 = rc::T10 * W[0][q] + rc::T11 * W[1][q] + rc::T12 * W[2][q];
-            const double z2 = W[0][q] + W[1][q];
-            double p0 = yc[q];                                        // PH_OUTER_BEGIN, PH_FNEW
-            if (phase == PH_F1) p0 = aux[q];
-            if (phase == PH_ERR_REFINE) p0 = yc[q] + aux[q];
-            if (newton) p0 = yc[q] + z0;
-            ye[0][q] = p0; ye[1][q] = yc[q] + z1; ye[2][q] = yc[q] + z2;
-        }
-        const RK k = fetch_reactor(ks);
-        if (__ballot(newton) != 0ull) {
-            // some reactor of the wavefront is in its Newton phase: all three stage points in one
-            // straight-line block (three independent chains for the scheduler to interleave); the
-            // other lanes' slot-1/2 results are simply not used
-            const bool b0 = rhs_full<ROW>(L, k, ye[0], Fe[0]);
-            const bool b1 = rhs_full<ROW>(L, k, ye[1], Fe[1]);
-            const bool b2 = rhs_full<ROW>(L, k, ye[2], Fe[2]);
-            if (eval0) { bad |= b0; if (phase != PH_FNEW) cnt.nfev++; }
-            if (newton) { bad |= b1 | b2; cnt.nfev += 2; }
-        } else if (__ballot(eval0) != 0ull) {
-            const bool b0 = rhs_full<ROW>(L, k, ye[0], Fe[0]);
-            if (eval0) { bad |= b0; if (phase != PH_FNEW) cnt.nfev++; }
-        }
-        if (__ballot(eval3) != 0ull) {
-            diag_f3++;
-            double fy[3];
-            const bool b3 = rhs_full<ROW>(L, k, yc, fy);
-            if (eval3) {
-                bad |= b3; pend_f = false;       // (counted in nfev when the step was accepted)
-#pragma unroll
-                for (int q = 0; q < 3; ++q) f[q] = fy[q];
-            }
-        }
-        if (seg_any(L, bad)) { bad = true; if (phase != PH_EXIT) phase = PH_OUTER_END; }
-        WT_STAMP(3);   // RHS evaluations
-
-        // ================= per-phase epilogues
-        if (phase == PH_OUTER_BEGIN) {
-#pragma unroll
-            for (int q = 0; q < 3; ++q) f[q] = Fe[0][q];
-            initial_step_first_half();
-            phase = PH_F1;
-        } else if (phase == PH_F1) {
-            double sc[3], df[3];
-#pragma unroll
-            for (int q = 0; q < 3; ++q) { sc[q] = ATOL + fabs(yc[q]) * RTOL; df[q] = Fe[0][q] - f[q]; }
-            const double d2 = rms3<ROW>(L, df, sc) * rcp(h0);
-            double h1;
-            if (d1 <= 1e-15 && d2 <= 1e-15) h1 = fmax(1e-6, h0 * 1e-3);
-            else h1 = root4(0.01 * rcp(fmax(d1, d2)));
-            h_abs = fmin(fmin(100 * h0, h1), fmin(fabs(t_bound - t), max_step));
-            need_jac = true;                                          // radau.py:359-365
-            phase = PH_STEP_BEGIN;
-        } else if (phase == PH_NEWTON) {
-            // ---- one iteration of solve_collocation_system radau.py:84-134
-            bool finite = true;
-#pragma unroll
-            for (int s = 0; s < 3; ++s)
-#pragma unroll
-                for (int q = 0; q < 3; ++q) finite = finite && isfinite(Fe[s][q]);
-            bool conv = false, diverged = false;
-            if (!seg_all(L, finite)) {
-                diverged = true;
-            } else {
-                const double ih = rcp(h);
-                const double M_real = rc::MU_REAL * ih, Mcr = rc::MU_CR * ih, Mci = rc::MU_CI * ih;
-                double fr[3], fcr[3], fci[3], scale[3];
-#pragma unroll
-                for (int q = 0; q < 3; ++q) {
-                    scale[q] = ATOL + fabs(yc[q]) * RTOL;
-                    fr[q] = (Fe[0][q] * rc::TI00 + Fe[1][q] * rc::TI01 + Fe[2][q] * rc::TI02) - M_real * W[0][q];
-                    const double re = Fe[0][q] * rc::TI10 + Fe[1][q] * rc::TI11 + Fe[2][q] * rc::TI12;
-                    const double im = Fe[0][q] * rc::TI20 + Fe[1][q] * rc::TI21 + Fe[2][q] * rc::TI22;
-                    fcr[q] = re - (Mcr * W[1][q] - Mci * W[2][q]);
-                    fci[q] = im - (Mcr * W[2][q] + Mci * W[1][q]);
-                }
-                solve_rc<ROW, LV>(L, J, F, fr, fcr, fci);
-                double ssum = 0.0;
-#pragma unroll
-                for (int q = 0; q < 3; ++q) {
-                    const double is = rcp(scale[q]);
-                    const double u = fr[q] * is, v = fcr[q] * is, w = fci[q] * is;
-                    ssum += u * u + v * v + w * w;
-                }
-                const double dW_norm = sqrt(seg_sum<ROW>(L, ssum) / (double)(9 * L.n));
-                if (have_norm_old) { rate = dW_norm * rcp(dW_norm_old); have_rate = true; }
-                const double i1r = rcp(1 - rate);
-                if (have_rate && (rate >= 1 || powi6(rate, NEWTON_MAXITER - kk) * i1r * dW_norm > rc::NEWTON_TOL)) {
-                    diverged = true;
-                } else {
-#pragma unroll
-                    for (int q = 0; q < 3; ++q) { W[0][q] += fr[q]; W[1][q] += fcr[q]; W[2][q] += fci[q]; }
-                    if (dW_norm == 0 || (have_rate && rate * i1r * dW_norm < rc::NEWTON_TOL)) conv = true;
-                    dW_norm_old = dW_norm; have_norm_old = true;
-                }
-            }
-            n_iter = kk + 1;
-            kk++;
-            if (!conv && !diverged && kk == NEWTON_MAXITER) diverged = true;   // loop ran out: radau.py:136
-            if (diverged) {                                                   // radau.py:462-476
-                if (current_jac) { h_abs_l *= 0.5; have_lu = false; cnt.nrej++; phase = PH_ATTEMPT; }
-                else { need_jac = true; current_jac = true; have_lu = false; keep_h = true; phase = PH_ATTEMPT; }
-            } else if (conv) {
-                // ---- error estimate radau.py:477-487
-                double err[3], esc[3];
-                const double ih_e = rcp(h);
+                for (int q = 0; q < 3; ++q) aux[q] = yc[q] + h0 * f[q];
+            };
+            // error_norm > 1: radau.py:489-496
+            auto reject_step = [&]() {
+                const double fct = predict_factor(h_abs_l, have_old_l, h_abs_old_l, error_norm, err_old_l);
+                h_abs_l *= fmax(MIN_FACTOR, safety * fct);
+                have_lu = false; rejected = true; cnt_s.nrej++;
+                phase = PH_ATTEMPT;
+            };
+            // step accepted: radau.py:500-539.  scipy evaluates f(y_new) right here; the value is first
+            // needed by the next error estimate, so unless a Jacobian refresh or the end of the outer
+            // step needs it at once, it is evaluated together with the next Newton trip (pend_f).
+            auto accept_step = [&]() {
+                const bool recompute_jac = (n_iter > 2) && have_rate && (rate > 1e-3);
+                double fct = predict_factor(h_abs_l, have_old_l, h_abs_old_l, error_norm, err_old_l);
+                fct = fmin(MAX_FACTOR, safety * fct);
+                if (!recompute_jac && fct < 1.2) fct = 1.0; else have_lu = false;
+                h_abs_old = h_abs;            // sic radau.py:520: the solver-level value
+                err_old = error_norm;
+                have_old = true;
+                h_abs = h_abs_l * fct;
 #pragma unroll
                 for (int q = 0; q < 3; ++q) {
                     const double z0 = rc::T00 * W[0][q] + rc::T01 * W[1][q] + rc::T02 * W[2][q];
                     const double z1 = rc::T10 * W[0][q] + rc::T11 * W[1][q] + rc::T12 * W[2][q];
                     const double z2 = W[0][q] + W[1][q];
-                    const double ZE = (z0 * rc::E0 + z1 * rc::E1 + z2 * rc::E2) * ih_e;
-                    err[q] = f[q] + ZE;
-                    esc[q] = ATOL + fmax(fabs(yc[q]), fabs(yc[q] + z2)) * RTOL;
+                    y_old[q] = yc[q];
+                    Q[q][0] = z0 * rc::P00 + z1 * rc::P10 + z2 * rc::P20;  // Q = Z^T P  radau.py:541-543
+                    Q[q][1] = z0 * rc::P01 + z1 * rc::P11 + z2 * rc::P21;
+                    Q[q][2] = z0 * rc::P02 + z1 * rc::P12 + z2 * rc::P22;
+                    yc[q] = yc[q] + z2;
                 }
-                solve_real<ROW, LV>(L, J, F, err);
-                error_norm = rms3<ROW>(L, err, esc);
-                safety = 0.9 * (2 * NEWTON_MAXITER + 1) / (2 * NEWTON_MAXITER + n_iter);
-                if (rejected && error_norm > 1) {
+                sol_t_old = t; sol_h = t_new - t; have_sol = true;
+                t = t_new;
+                cnt_s.nsteps++; cnt_s.nfev++;     // f(y_new) counted where scipy calls it
+                pend_f = true; fv = false;
+                current_jac = recompute_jac;
+                const bool more = (t - t_bound) < 0;
+                if (recompute_jac || !more) { jac_after_fnew = recompute_jac; phase = PH_FNEW; }
+                else phase = PH_STEP_BEGIN;
+            };
+
+            if (fv) {
+                // f(y0) is already in f (last evaluation of the previous outer step, same y, same
+                // boundary): count it as scipy does and go straight to the initial-step probe
+                cnt_s.nfev++;
+                phase = PH_INIT_STEP;
+            }
+
+            while (true) {
+                // reactors that finished their outer step wait here until every reactor of the wavefront has
+                if (__ballot(phase != PH_DONE) == 0ull) break;
+                // ================= trips that need no RHS evaluation (run first so the lane can join this trip's evaluation)
+                if (phase == PH_INIT_STEP) {      // the one copy of this arithmetic, whether f0 was evaluated or carried over
+                    initial_step_first_half();
+                    phase = PH_F1;
+                }
+                if (phase == PH_STEP_BEGIN) {
+                    min_step = 10 * fabs(ulp_above(t));                      // radau.py:408
+                    if (h_abs > max_step) { h_abs_l = max_step; have_old_l = false; }
+                    else if (h_abs < min_step) { h_abs_l = min_step; have_old_l = false; }
+                    else { h_abs_l = h_abs; have_old_l = have_old; h_abs_old_l = h_abs_old; err_old_l = err_old; }
+                    rejected = false; keep_h = false;
+                    phase = PH_ATTEMPT;
+                }
+                if (phase == PH_ATTEMPT) {
+                    if (!keep_h) {
+                        if (step_limit > 0 && attempts >= step_limit) { failed = true; limit_hit = true; phase = PH_DONE; }
+                        else if (h_abs_l < min_step) { failed = true; phase = PH_DONE; }  // radau.py:427-428
+                        else {
+                            attempts++;
+                            h = h_abs_l;
+                            t_new = t + h;
+                            if (t_new - t_bound > 0) t_new = t_bound;
+                            h = t_new - t;
+                            h_abs_l = fabs(h);
+                        }
+                    }
+                    if (phase == PH_ATTEMPT) {
+                        keep_h = false;
+                        // initial guess Z0 (radau.py:445-448,557-572) and W = TI Z0 (radau.py:88)
+                        double Z0[3][3];
+                        if (!have_sol) {
 #pragma unroll
-                    for (int q = 0; q < 3; ++q) aux[q] = err[q];
-                    phase = PH_ERR_REFINE;
-                } else if (error_norm > 1) {                                  // radau.py:489-496
-                    reject_step();
+                            for (int s = 0; s < 3; ++s)
+#pragma unroll
+                                for (int q = 0; q < 3; ++q) Z0[s][q] = 0.0;
+                        } else {
+                            const double isol = rcp(sol_h);
+                            const double cs[3] = {rc::C0, rc::C1, 1.0};
+#pragma unroll
+                            for (int s = 0; s < 3; ++s) {
+                                const double x = ((t + h * cs[s]) - sol_t_old) * isol;
+                                const double p1 = x * x, p2 = p1 * x;
+#pragma unroll
+                                for (int q = 0; q < 3; ++q)
+                                    Z0[s][q] = ((Q[q][0] * x + Q[q][1] * p1 + Q[q][2] * p2) + y_old[q]) - yc[q];
+                            }
+                        }
+#pragma unroll
+                        for (int q = 0; q < 3; ++q) {
+                            W[0][q] = rc::TI00 * Z0[0][q] + rc::TI01 * Z0[1][q] + rc::TI02 * Z0[2][q];
+                            W[1][q] = rc::TI10 * Z0[0][q] + rc::TI11 * Z0[1][q] + rc::TI12 * Z0[2][q];
+                            W[2][q] = rc::TI20 * Z0[0][q] + rc::TI21 * Z0[1][q] + rc::TI22 * Z0[2][q];
+                        }
+                        kk = 0; have_norm_old = false; have_rate = false; rate = 0.0;
+                        phase = PH_NEWTON;
+                    }
+                }
+                if (__ballot(phase == PH_NEWTON && !have_lu) != 0ull) diag_fact++;
+                if (phase == PH_NEWTON && !have_lu) {
+                    factorize<ROW, LV>(L, J, h, F); have_lu = true; cnt_s.nlu += 2;      // radau.py:454-456
+                }
+
+                // ================= this trip's evaluation points
+                const bool newton = (phase == PH_NEWTON);
+                diag_trips++; if (__ballot(newton) != 0ull) diag_newton++;
+                const bool eval0 = (phase == PH_OUTER_BEGIN || phase == PH_F1 || phase == PH_ERR_REFINE || phase == PH_FNEW || newton);
+                // f(y) of a just-accepted step rides along with the next attempt's first Newton trip
+                const bool eval3 = newton && pend_f;
+                double ye[3][3], Fe[3][3];
+                // Z = T W (radau.py:124): Z[2] = W0 + W1
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const double z0 = rc::T00 * W[0][q] + rc::T01 * W[1][q] + rc::T02 * W[2][q];
+                    const double z1 = rc::T10 * W[0][q] + rc::T11 * W[1][q] + rc::T12 * W[2][q];
+                    const double z2 = W[0][q] + W[1][q];
+                    double p0 = yc[q];                                        // PH_OUTER_BEGIN, PH_FNEW
+                    if (phase == PH_F1) p0 = aux[q];
+                    if (phase == PH_ERR_REFINE) p0 = yc[q] + aux[q];
+                    if (newton) p0 = yc[q] + z0;
+                    ye[0][q] = p0; ye[1][q] = yc[q] + z1; ye[2][q] = yc[q] + z2;
+                }
+                const RK kr = fetch_reactor(ks);
+                bool b0 = false, b1 = false, b2 = false, b3 = false;
+                if (__ballot(newton) != 0ull) {
+                    // some reactor of the wavefront is in its Newton phase: all three stage points in one
+                    // straight-line block (three independent chains for the scheduler to interleave); the
+                    // other lanes' slot-1/2 results are simply not used
+                    b0 = rhs_full<ROW>(L, kr, ye[0], Fe[0]);
+                    b1 = rhs_full<ROW>(L, kr, ye[1], Fe[1]);
+                    b2 = rhs_full<ROW>(L, kr, ye[2], Fe[2]);
+                    b0 = b0 && eval0; b1 = b1 && newton; b2 = b2 && newton;
+                    if (eval0 && phase != PH_FNEW) cnt_s.nfev++;
+                    if (newton) cnt_s.nfev += 2;
+                } else if (__ballot(eval0) != 0ull) {
+                    b0 = rhs_full<ROW>(L, kr, ye[0], Fe[0]) && eval0;
+                    if (eval0 && phase != PH_FNEW) cnt_s.nfev++;
+                }
+                if (__ballot(eval3) != 0ull) {
+                    diag_f3++;
+                    double fy[3];
+                    b3 = rhs_full<ROW>(L, kr, yc, fy) && eval3;
+                    if (eval3) {
+                        pend_f = false;       // (counted in nfev when the step was accepted)
+#pragma unroll
+                        for (int q = 0; q < 3; ++q) f[q] = fy[q];
+                    }
+                }
+                if (__ballot(b0 || b1 || b2 || b3) != 0ull) {   // rare: a zone temperature outside [0, 100] C
+                    // the reference raises in the first evaluation, at the first zone, that sees it: scipy calls
+                    // f(y_new) of the accepted step before the stages of the next Newton iteration
+                    const bool mine = b0 || b1 || b2 || b3;
+                    if (mine && !bad) {
+                        badstage = b3 ? 0 : (b0 ? 1 : (b1 ? 2 : 3));
+                        badval = b3 ? yc[STT] : (b0 ? ye[0][STT] : (b1 ? ye[1][STT] : ye[2][STT]));
+                    }
+                    bad |= mine;
+                    if (seg_any(L, bad)) { raised = true; phase = PH_DONE; }
+                }
+
+                // ================= per-phase epilogues
+                if (phase == PH_OUTER_BEGIN) {
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) f[q] = Fe[0][q];
+                    phase = PH_INIT_STEP;
+                } else if (phase == PH_F1) {
+                    double sc[3], df[3];
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) { sc[q] = ATOL + fabs(yc[q]) * RTOL; df[q] = Fe[0][q] - f[q]; }
+                    const double d2 = rms3<ROW>(L, df, sc) * rcp(h0);
+                    double h1;
+                    if (d1 <= 1e-15 && d2 <= 1e-15) h1 = fmax(1e-6, h0 * 1e-3);
+                    else h1 = root4(0.01 * rcp(fmax(d1, d2)));
+                    h_abs = fmin(fmin(100 * h0, h1), fmin(fabs(t_bound - t), max_step));
+                    need_jac = true;                                          // radau.py:359-365
+                    phase = PH_STEP_BEGIN;
+                } else if (phase == PH_NEWTON) {
+                    // ---- one iteration of solve_collocation_system radau.py:84-134
+                    bool finite = true;
+#pragma unroll
+                    for (int s = 0; s < 3; ++s)
+#pragma unroll
+                        for (int q = 0; q < 3; ++q) finite = finite && isfinite(Fe[s][q]);
+                    bool conv = false, diverged = false;
+                    if (!seg_all(L, finite)) {
+                        diverged = true;
+                    } else {
+                        const double ih = rcp(h);
+                        const double M_real = rc::MU_REAL * ih, Mcr = rc::MU_CR * ih, Mci = rc::MU_CI * ih;
+                        double fr[3], fcr[3], fci[3], scale[3];
+#pragma unroll
+                        for (int q = 0; q < 3; ++q) {
+                            scale[q] = ATOL + fabs(yc[q]) * RTOL;
+                            fr[q] = (Fe[0][q] * rc::TI00 + Fe[1][q] * rc::TI01 + Fe[2][q] * rc::TI02) - M_real * W[0][q];
+                            const double re = Fe[0][q] * rc::TI10 + Fe[1][q] * rc::TI11 + Fe[2][q] * rc::TI12;
+                            const double im = Fe[0][q] * rc::TI20 + Fe[1][q] * rc::TI21 + Fe[2][q] * rc::TI22;
+                            fcr[q] = re - (Mcr * W[1][q] - Mci * W[2][q]);
+                            fci[q] = im - (Mcr * W[2][q] + Mci * W[1][q]);
+                        }
+                        solve_rc<ROW, LV>(L, J, F, fr, fcr, fci);
+                        double ssum = 0.0;
+#pragma unroll
+                        for (int q = 0; q < 3; ++q) {
+                            const double is = rcp(scale[q]);
+                            const double u = fr[q] * is, v = fcr[q] * is, w = fci[q] * is;
+                            ssum += u * u + v * v + w * w;
+                        }
+                        const double dW_norm = sqrt(seg_sum<ROW>(L, ssum) / (double)(9 * L.n));
+                        if (have_norm_old) { rate = dW_norm * rcp(dW_norm_old); have_rate = true; }
+                        const double i1r = rcp(1 - rate);
+                        if (have_rate && (rate >= 1 || powi6(rate, NEWTON_MAXITER - kk) * i1r * dW_norm > rc::NEWTON_TOL)) {
+                            diverged = true;
+                        } else {
+#pragma unroll
+                            for (int q = 0; q < 3; ++q) { W[0][q] += fr[q]; W[1][q] += fcr[q]; W[2][q] += fci[q]; }
+                            if (dW_norm == 0 || (have_rate && rate * i1r * dW_norm < rc::NEWTON_TOL)) conv = true;
+                            dW_norm_old = dW_norm; have_norm_old = true;
+                        }
+                    }
+                    n_iter = kk + 1;
+                    kk++;
+                    if (!conv && !diverged && kk == NEWTON_MAXITER) diverged = true;   // loop ran out: radau.py:136
+                    if (diverged) {                                                   // radau.py:462-476
+                        if (current_jac) { h_abs_l *= 0.5; have_lu = false; cnt_s.nrej++; phase = PH_ATTEMPT; }
+                        else { need_jac = true; current_jac = true; have_lu = false; keep_h = true; phase = PH_ATTEMPT; }
+                    } else if (conv) {
+                        // ---- error estimate radau.py:477-487
+                        double err[3], esc[3];
+                        const double ih_e = rcp(h);
+#pragma unroll
+                        for (int q = 0; q < 3; ++q) {
+                            const double z0 = rc::T00 * W[0][q] + rc::T01 * W[1][q] + rc::T02 * W[2][q];
+                            const double z1 = rc::T10 * W[0][q] + rc::T11 * W[1][q] + rc::T12 * W[2][q];
+                            const double z2 = W[0][q] + W[1][q];
+                            const double ZE = (z0 * rc::E0 + z1 * rc::E1 + z2 * rc::E2) * ih_e;
+                            err[q] = f[q] + ZE;
+                            esc[q] = ATOL + fmax(fabs(yc[q]), fabs(yc[q] + z2)) * RTOL;
+                        }
+                        solve_real<ROW, LV>(L, J, F, err);
+                        error_norm = rms3<ROW>(L, err, esc);
+                        safety = 0.9 * (2 * NEWTON_MAXITER + 1) / (2 * NEWTON_MAXITER + n_iter);
+                        if (rejected && error_norm > 1) {
+#pragma unroll
+                            for (int q = 0; q < 3; ++q) aux[q] = err[q];
+                            phase = PH_ERR_REFINE;
+                        } else if (error_norm > 1) {                                  // radau.py:489-496
+                            reject_step();
+                        } else {
+                            accept_step();
+                        }
+                    }
+                } else if (phase == PH_ERR_REFINE) {
+                    double err[3], esc[3];
+                    const double ih_e = rcp(h);
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) {
+                        const double z0 = rc::T00 * W[0][q] + rc::T01 * W[1][q] + rc::T02 * W[2][q];
+                        const double z1 = rc::T10 * W[0][q] + rc::T11 * W[1][q] + rc::T12 * W[2][q];
+                        const double z2 = W[0][q] + W[1][q];
+                        const double ZE = (z0 * rc::E0 + z1 * rc::E1 + z2 * rc::E2) * ih_e;
+                        err[q] = Fe[0][q] + ZE;
+                        esc[q] = ATOL + fmax(fabs(yc[q]), fabs(yc[q] + z2)) * RTOL;
+                    }
+                    solve_real<ROW, LV>(L, J, F, err);
+                    error_norm = rms3<ROW>(L, err, esc);
+                    if (error_norm > 1) reject_step(); else accept_step();
+                } else if (phase == PH_FNEW) {
+                    // f(y_new) of an accepted step that needs it before anything else can happen:
+                    // Jacobian refresh (radau.py:512-514) or the end of the outer step
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) f[q] = Fe[0][q];
+                    pend_f = false;
+                    fv = true;
+                    if (jac_after_fnew) { need_jac = true; jac_after_fnew = false; }
+                    phase = ((t - t_bound) < 0) ? PH_STEP_BEGIN : PH_DONE;
+                }
+
+                // ================= finite-difference Jacobian at (yc, f) when a phase asked for it
+                if (__ballot(need_jac) != 0ull) diag_jac++;
+                if (need_jac) {
+                    bool jbad = false, hf = have_fac; double jval = 0;
+                    asm volatile("" ::: "memory");               // a fresh fetch: do not keep the constants live across the epilogue
+                    const RK kj = fetch_reactor(ks);
+                    num_jac<ROW>(L, kj, yc, f, fac, hf, J, jbad, jval); cnt_s.njev++;
+                    have_fac = hf;
+                    need_jac = false;
+                    if (seg_any(L, jbad)) {
+                        if (jbad && !bad) { badstage = 4; badval = jval; }
+                        bad |= jbad; raised = true; phase = PH_DONE;
+                    }
+                }
+            }
+            last_cnt = cnt_s;
+
+            // ================= after the solve: reactor.py:486-507
+            if (raised) {
+                // the reference raised (thermodynamics.py:146-157): self.state untouched; name the temperature its
+                // message names -- first evaluation of the trip, lowest zone
+                st |= ST_T_RANGE; frozen = true;
+                double v = badval; int best = 1 << 30;
+#pragma unroll 1
+                for (int sidx = 0; sidx < 5; ++sidx) {
+                    const unsigned long long m = __ballot(bad && badstage == sidx) & L.segmask;
+                    if (m != 0ull && best == (1 << 30)) { best = sidx; v = __shfl(badval, (int)__builtin_ctzll(m), 64); }
+                }
+                badval = v;
+                raised = false;
+            } else {
+                if (failed) st |= ST_SOLVER_FAILED;    // reactor.py:486-487; state <- last accepted y
+                if (limit_hit) st |= ST_STEP_LIMIT;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) y0[q] = yc[q];
+                stepped = true; steps_done++;
+                t_out = t_out + dt;                    // reactor.py:496
+                flow_used = ks.uni[15 * RK_MAXR];      // reactor.py:497-501
+                // _update_derived_state reactor.py:511-524 (before the clamp)
+                dH = exp10(-y0[SPH]);
+                const PropT pt = prop_T(y0[STT]);
+                dR = pt.rho;
+                bool clamped = false;
+                if (seg_any(L, pt.bad)) {
+                    st |= ST_T_RANGE_POST; frozen = true;
+                    const unsigned long long m = __ballot(pt.bad) & L.segmask;
+                    badval = __shfl(y0[STT], (int)__builtin_ctzll(m), 64);
                 } else {
-                    accept_step();
+                    dK = pt.kT; wrote_k = true;
+                    // _enforce_physical_bounds reactor.py:526-541
+                    if (seg_any(L, y0[SPH] < 0 || y0[SPH] > 14)) { st |= ST_CLAMP_PH; y0[SPH] = fmin(fmax(y0[SPH], 0.0), 14.0); clamped = true; }
+                    if (seg_any(L, y0[SCL] < 0)) { st |= ST_CLAMP_CL; y0[SCL] = fmax(y0[SCL], 0.0); clamped = true; }
+                    if (seg_any(L, y0[STT] < 0 || y0[STT] > 100)) { st |= ST_CLAMP_T; y0[STT] = fmin(fmax(y0[STT], 0.0), 100.0); clamped = true; }
+                    // f(y) of the last accepted point is f0 of the next outer step when nothing touched y
+                    f_valid = fv && !clamped && !failed;
                 }
             }
-        } else if (phase == PH_ERR_REFINE) {
-            double err[3], esc[3];
-            const double ih_e = rcp(h);
-#pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                const double z0 = rc::T00 * W[0][q] + rc::T01 * W[1][q] + rc::T02 * W[2][q];
-                const double z1 = rc::T10 * W[0][q] + rc::T11 * W[1][q] + rc::T12 * W[2][q];
-                const double z2 = W[0][q] + W[1][q];
-                const double ZE = (z0 * rc::E0 + z1 * rc::E1 + z2 * rc::E2) * ih_e;
-                err[q] = Fe[0][q] + ZE;
-                esc[q] = ATOL + fmax(fabs(yc[q]), fabs(yc[q] + z2)) * RTOL;
+          }
+        }
+
+        // ================= what follows reactor.step() in the reference's loop body (__main__.py:403-423)
+        if (sens_on) {
+            ArgPtr b = fresh(pa);            // ---- section: sensors and plant I/O
+            __syncthreads();                 // the factor store is dead now; the same LDS carries the hand-off
+            if (seg < R) {
+                const bool live = stepped && !(st & ST_T_RANGE_POST);     // the reference's loop stops where step() raises
+                if (L.z == 0) {
+                    io.stepped[seg] = live ? 1 : 0;
+                    io.t_after[seg] = t_out;
+                    io.tap[0][seg] = (float)y0[SPH]; io.tap[2][seg] = (float)y0[SCL]; io.tap[4][seg] = (float)y0[STT];
+                    io.tap[6][seg] = (float)flow_used;
+                }
+                if (!L.has_hi) { io.tap[1][seg] = (float)y0[SPH]; io.tap[3][seg] = (float)y0[SCL]; io.tap[5][seg] = (float)y0[STT]; }
             }
-            solve_real<ROW, LV>(L, J, F, err);
-            error_norm = rms3<ROW>(L, err, esc);
-            if (error_norm > 1) reject_step(); else accept_step();
-        } else if (phase == PH_FNEW) {
-            // f(y_new) of an accepted step that needs it before anything else can happen:
-            // Jacobian refresh (radau.py:512-514) or the end of the outer step
-#pragma unroll
-            for (int q = 0; q < 3; ++q) f[q] = Fe[0][q];
-            pend_f = false;
-            f_valid = true;
-            if (jac_after_fnew) { need_jac = true; jac_after_fnew = false; }
-            phase = ((t - t_bound) < 0) ? PH_STEP_BEGIN : PH_OUTER_END;
+            __syncthreads();
+            wts::suite_step(b->sens, io, r_first, R, hist0, k);          // read_all_sensors
+            if (plc_on) {
+                const int gs = b->first_step + step0 + k;
+                const bool scan = ((gs + 1) % b->sens.scan_every == 0) || (gs + 1 == b->call_steps);
+                __syncthreads();
+                if (lane < R && io.stepped[lane]) {                       // one lane per reactor
+                    const int64_t rr = r_first + lane;
+                    const double lt = b->sens.pack.loop_time[rr];
+                    if (scan) {
+                        wtp::pack_inputs(b->sens.pack, rr, &io.val[0][lane], &io.fault[0][lane], wts::RMAX, lt);   // update_modbus_inputs
+                        double c[3];
+                        wtp::apply_commands(b->sens.cmd, rr, c);         // read_modbus_commands + apply_boundary_conditions
+                        io.cmd[0][lane] = c[0]; io.cmd[1][lane] = c[1]; io.cmd[2][lane] = c[2];
+                    }
+                    b->sens.pack.loop_time[rr] = lt + dt;                 // sim_time += dt (__main__.py:446)
+                }
+                if (scan) {
+                    __syncthreads();
+                    if (present && io.stepped[seg]) {                    // the next step integrates under the new setpoints
+                        RK k0; load_reactor(b->par, b->bc, b->N, r, n_zones, k0, &io.cmd[0][seg], wts::RMAX); mask_reactor_for_lane(L, k0);
+                        park_reactor(ks, k0);
+                        f_valid = false;
+                    }
+                }
+            }
+            __syncthreads();                 // hand-off read; the next step's factors may overwrite it
         }
-
-        WT_STAMP(4);   // epilogues (Newton solve, error estimate, accept / reject)
-        // ================= finite-difference Jacobian at (yc, f) when a phase asked for it
-        if (__ballot(need_jac) != 0ull) diag_jac++;
-        if (need_jac) {
-            bool jbad = false, hf = have_fac;
-            asm volatile("" ::: "memory");               // a fresh fetch: do not keep the constants live across the epilogue
-            const RK kj = fetch_reactor(ks);
-            num_jac<ROW>(L, kj, yc, f, fac, hf, J, jbad); cnt.njev++;
-            have_fac = hf;
-            need_jac = false;
-            if (seg_any(L, jbad)) { bad = true; phase = PH_OUTER_END; }
-        }
-        WT_STAMP(5);   // num_jac
     }
 
-    if (a.wave_diag && (threadIdx.x & 63) == 0) {
-        int64_t *o = a.wave_diag + (a.r0 / a.R + (int64_t)blockIdx.x) * WT_DIAG_SLOTS;
-        o[0] = diag_trips; o[1] = diag_newton; o[4] = diag_fact; o[5] = diag_jac; o[6] = diag_f3; o[7] = 0;
-#ifdef WT_STAMPS
-        for (int i = 0; i < 8; ++i) o[8 + i] = sec[i];
-#endif
-        o[2] = __builtin_amdgcn_s_memtime() - clk0; o[3] = __builtin_amdgcn_s_memrealtime() - wall0;
-    }
-    if (advanced) {
-        a.pH[idx] = y0[SPH]; a.Cl[idx] = y0[SCL]; a.T[idx] = y0[STT];
-        a.dH[idx] = dH; a.dRho[idx] = dR;
-        if (wrote_k) a.dK[idx] = dK;
-    }
-    if (L.z == 0) {
-        if (advanced) {
-            a.time[r] = t_out;
-            // reactor.py:497-501
-            a.flow[r] = a.bc[0 * a.N + r] + a.bc[4 * a.N + r] + a.bc[6 * a.N + r];
+    // ================= the item's results
+    ArgPtr c = fresh(pa);
+    if (present) {
+        if (steps_done > 0) {
+            c->pH[idx] = y0[SPH]; c->Cl[idx] = y0[SCL]; c->T[idx] = y0[STT];
+            c->dH[idx] = dH; c->dRho[idx] = dR;
+            if (wrote_k) c->dK[idx] = dK;
         }
-        a.status[r] = st;
-        if (a.tap_count) a.tap_count[r] = a.n_steps - steps_left;
-        if (a.stats) {
-            int32_t *o = a.stats + r * 5;
-            o[0] = cnt.nfev; o[1] = cnt.njev; o[2] = cnt.nlu; o[3] = cnt.nsteps; o[4] = cnt.nrej;
+        if (L.z == 0) {
+            if (steps_done > 0) {
+                c->time[r] = t_out;
+                c->flow[r] = flow_used;
+                if (c->stats) {
+                    int32_t *o = c->stats + r * 5;
+                    o[0] = last_cnt.nfev; o[1] = last_cnt.njev; o[2] = last_cnt.nlu; o[3] = last_cnt.nsteps; o[4] = last_cnt.nrej;
+                }
+                if (sens_on && c->sens.hist_value) c->sens.hist_pos[r] = hist0[seg] + steps_done;
+            }
+            c->status[r] = st;
+            if (st & (ST_T_RANGE | ST_T_RANGE_POST)) c->bad_T[r] = badval;
         }
+    }
+    if (want_diag && lane == 0) {
+        unsigned long long *o = reinterpret_cast<unsigned long long *>(c->wave_diag + (int64_t)group * WT_DIAG_SLOTS);
+        atomicAdd(o + 0, (unsigned long long)diag_trips); atomicAdd(o + 1, (unsigned long long)diag_newton);
+        atomicAdd(o + 2, (unsigned long long)(__builtin_amdgcn_s_memtime() - clk0));
+        atomicAdd(o + 3, (unsigned long long)(__builtin_amdgcn_s_memrealtime() - wall0));
+        atomicAdd(o + 4, (unsigned long long)diag_fact); atomicAdd(o + 5, (unsigned long long)diag_jac);
+        atomicAdd(o + 6, (unsigned long long)diag_f3); atomicAdd(o + 7, 1ull);
+    }
+}
+
+// The physics kernel.  Queue schedule: a grid of worker wavefronts that take (wavefront-group, next few outer
+// steps) items from a device-side FIFO until the whole ensemble has advanced n_steps -- one launch, no launch
+// tails: a slow wavefront delays nobody, and with more groups than resident wavefronts every SIMD stays busy.
+// Stream schedule (q_ctrl == nullptr): workgroup b advances group r0 / R + b by n_steps and exits.
+template <int LV, bool ROW>
+__global__ __launch_bounds__(64) void step_kernel(const StepArgs a)
+{
+    __shared__ double lds[LdsMap<LV>::TOTAL];
+    Lane L;
+    lane_geometry(a.n, L);
+    // the by-value argument block sits at offset 0 of the kernel-argument segment
+    const ArgPtr pa = (ArgPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    if (!a.q_ctrl) {
+        run_item<LV, ROW>(pa, L, lds, (int)(a.r0 / a.R) + (int)blockIdx.x, 0, a.n_steps);
+        return;
+    }
+    int group = queue_next(a, -1);
+    while (group >= 0) {
+        // the previous worker's release (queue_push) -> this acquire -> plain loads of the group's state
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        int step0 = 0;
+        if ((threadIdx.x & 63) == 0) step0 = __hip_atomic_load(a.q_next + group, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        step0 = __builtin_amdgcn_readfirstlane(step0);
+        const int left = a.n_steps - step0;
+        const int cnt = left < a.item_steps ? left : a.item_steps;
+        run_item<LV, ROW>(pa, L, lds, group, step0, cnt);
+        const bool more = step0 + cnt < a.n_steps;
+        // publish the group's state before anybody can take its next item
+        if ((threadIdx.x & 63) == 0) __hip_atomic_store(a.q_next + group, step0 + cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        group = queue_next(a, more ? group : -1);
     }
 }
 
@@ -1303,6 +1529,15 @@ __global__ __launch_bounds__(64) void rhs_kernel(const RhsArgs a)
     a.dpH[idx] = f[SPH]; a.dCl[idx] = f[SCL]; a.dT[idx] = f[STT];
     const bool anybad = seg_any(L, bad);
     if (L.z == 0) a.flags[r] = anybad ? ST_T_RANGE : 0u;
+}
+
+// ReactorState.update_derived placeholders after the state was overwritten (reactor.py:137-147)
+struct PlaceholderArgs { int64_t count; const double *pH; double *dH, *dRho, *dK; };
+__global__ __launch_bounds__(256) void derived_placeholder_kernel(const PlaceholderArgs a)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.count) return;
+    a.dH[i] = exp10(-a.pH[i]); a.dRho[i] = 998.2; a.dK[i] = 0.0001;
 }
 
 // Self-test of the cross-lane primitives against ds_bpermute-based __shfl:

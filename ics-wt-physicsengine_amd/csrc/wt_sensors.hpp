@@ -13,13 +13,14 @@
 //   FlowSensor.read            sensors/flow_sensor.py:125-219     (magnetic)
 //   TemperatureSensor.read     sensors/temperature_sensor.py:110-171 (RTD Pt100)
 //
-// Mapping: one thread per (reactor, sensor group) -- the suite splits into five groups that do not
-// interact (two of them hold the two sensors that share a delay line) -- structure-of-arrays state so
-// that lane r of a wavefront touches word r of every state row; the kernel is a byte mover, bound by
-// HBM/L2 bandwidth.  Signal path in fp32 (config 5); time and the slow ageing accumulators in fp64.
-// Input: per-step "taps" (pH, Cl, T of zones 0 and n-1, flow) written by the physics kernel for the
-// steps of one launch, so the suite sees every outer step although the physics keeps its state in
-// registers across them.
+// Mapping: the suite runs INSIDE the physics kernel (wt_device.hpp) at the end of every outer step, on the
+// lanes of the wavefront that has just integrated the reactors: the seven taps the sensors look at (pH, Cl, T
+// of zones 0 and n-1, flow) go from the physics lanes' registers through a few hundred bytes of LDS to the
+// sensor lanes -- no tap buffer in HBM, no second kernel.  The suite splits into five groups that do not
+// interact (two of them hold the two sensors that share a delay line, read one after the other as
+// read_all_sensors does); lane l of a pass runs group l / R of reactor l % R of the wavefront's R reactors.
+// Sensor state is structure-of-arrays in HBM (L2-resident), read and written back by the same lane every step.
+// Signal path in fp32 (config 5); time and the slow ageing accumulators in fp64.
 //
 // Randomness: the reference seeds numpy from `secrets`; here every rng.normal / rng.random /
 // rng.choice of the reference is one draw of Philox4x32-10 with key = suite seed and
@@ -47,16 +48,16 @@ enum { ST_NORMAL = 0, ST_CALIBRATING, ST_WARMING_UP, ST_FAILED, ST_SATURATED, ST
 enum { FL_NONE = 0, FL_OPEN_CIRCUIT, FL_SHORT_CIRCUIT, FL_OUT_OF_RANGE, FL_RATE_FAULT, FL_POWER_LOW, FL_POWER_HIGH };
 enum { K_PH = 0, K_CL_AMP, K_CL_DPD, K_FLOW_MAG, K_T_RTD };
 
-struct SensorArgs {
+constexpr int RMAX = 32;         // reactors per wavefront at n = 2
+
+// Everything the suite touches in HBM, SoA with the reactor index fastest.
+struct SuiteArgs {
+    int on;                // 0: no sensor suite attached to this ensemble
+    int plc_on;            // publish the readings into the Modbus images and run the command path (wt_plc.hpp)
+    int scan_every;        // PLC scan interval in outer steps (a scan also closes every wt_ensemble_step call)
     int64_t N;             // reactors in the ensemble (row stride)
-    int64_t r0, r1;        // this launch handles reactors [r0, r1)
     int64_t reactor_base;  // global index of reactor 0 (sharded ensembles keep distinct streams)
     uint32_t seed_lo, seed_hi;
-    int n_steps;           // taps of this launch
-    double dt;
-    const float *taps;     // [n_steps][NTAP][N]
-    const int32_t *tap_count; // [N] outer steps the physics completed in this launch
-    const double *time_end;   // [N] ReactorState.time after the launch
     const double *t_enable;   // [N] ReactorState.time when the suite was enabled (calibration time)
     float *fs;             // [NSENS][NF][N]
     double *ds;            // [NSENS][ND][N]
@@ -69,12 +70,21 @@ struct SensorArgs {
     float *hist_value;     // optional [hist_cap][NSENS][N]
     uint8_t *hist_status, *hist_fault;
     int hist_cap;
-    int32_t *hist_pos;     // [NGROUP][N] next history slot (one copy per sensor group, all equal)
-    int32_t *arrive;       // arrival counters of the reactor blocks (zero between launches)
-    int64_t arrive_base;   // first counter of this launch's reactor range
-    int plc_on;            // publish the readings into the Modbus images and run the command path (wt_plc.hpp)
+    int32_t *hist_pos;     // [N] reads taken so far (next history slot)
     wtp::PackArgs pack;
     wtp::CommandArgs cmd;
+};
+
+// One wavefront's per-step hand-off between the lanes that integrate (one per zone), the lanes that run the
+// sensor groups and the lanes that publish the register image (one per reactor).  Lives in LDS, on top of
+// the tridiagonal-factor store, which is dead between two outer steps.
+struct StepIO {
+    float tap[NTAP][RMAX];      // pH0, pHN, Cl0, ClN, T0, TN, flow as the sensors see them (fp32)
+    double t_after[RMAX];       // ReactorState.time after the step
+    int stepped[RMAX];          // the reactor completed this outer step (frozen / absent reactors are not read)
+    float val[NSENS][RMAX];     // this step's readings, for the register image
+    int fault[NSENS][RMAX];
+    double cmd[3][RMAX];        // boundary rows in force after the command path: inlet, acid, chlorine flow
 };
 
 // ---------------------------------------------------------------- Philox4x32-10
@@ -140,7 +150,7 @@ struct SState {
     Rng rng;
 };
 
-__device__ __forceinline__ SState load_state(const SensorArgs &a, int i, int64_t r)
+template <class A> __device__ __forceinline__ SState load_state(const A &a, int i, int64_t r)
 {
     const int64_t N = a.N;
     const float *F = a.fs + ((int64_t)i * NF) * N + r; const double *D = a.ds + ((int64_t)i * ND) * N + r;
@@ -154,7 +164,7 @@ __device__ __forceinline__ SState load_state(const SensorArgs &a, int i, int64_t
     return s;
 }
 
-__device__ __forceinline__ void store_state(const SensorArgs &a, int i, int64_t r, const SState &s)
+template <class A> __device__ __forceinline__ void store_state(const A &a, int i, int64_t r, const SState &s)
 {
     const int64_t N = a.N;
     float *F = a.fs + ((int64_t)i * NF) * N + r; double *D = a.ds + ((int64_t)i * ND) * N + r; int32_t *I = a.is + ((int64_t)i * NI) * N + r;
@@ -193,12 +203,14 @@ struct Line {
     }
 };
 
-// One BaseSensor.read + type-specific read() of sensor I at time t.
-template <int I>
-__device__ __forceinline__ void read_sensor(SState &s, Line &ln, const float *tap, int64_t N, double t, float fs,
+// One BaseSensor.read + type-specific read() of sensor `sensor` at time t.  `tap` points at this reactor's
+// column of StepIO::tap (stride RMAX); lanes of one call run different sensors, so every branch on the
+// sensor kind is a lane mask.
+__device__ __forceinline__ void read_sensor(int sensor, SState &s, Line &ln, const float *tap, double t, float fs,
                                             float &value, int &rstatus, int &rfault)
 {
-    const SensorSpec sp = spec_of(I, fs);
+    constexpr int N = RMAX;
+    const SensorSpec sp = spec_of(sensor, fs);
     value = __builtin_nanf("");
     // ---------------- BaseSensor.read
     if (!(20.0f < s.supply && s.supply < 28.0f)) {                               // :549-569 (and stays so)
@@ -308,83 +320,49 @@ __device__ __forceinline__ void read_sensor(SState &s, Line &ln, const float *ta
     s.current = fin; s.last_value = fin; value = fin;
 }
 
-__device__ __forceinline__ void emit(const SensorArgs &a, int i, int64_t r, int k, int steps, int hist0,
-                                     float value, int rstatus, int rfault)
+template <class A> __device__ __forceinline__ void emit(const A &a, int i, int64_t r, int pos, float value, int rstatus, int rfault)
 {
     const int64_t N = a.N;
-    if (k == steps - 1) { a.out_value[(int64_t)i * N + r] = value; a.out_status[(int64_t)i * N + r] = (uint8_t)rstatus; a.out_fault[(int64_t)i * N + r] = (uint8_t)rfault; }
-    if (a.hist_value) {
-        const int pos = hist0 + k;
-        if (pos < a.hist_cap) {
-            const int64_t o = ((int64_t)pos * NSENS + i) * N + r;
-            a.hist_value[o] = value; a.hist_status[o] = (uint8_t)rstatus; a.hist_fault[o] = (uint8_t)rfault;
-        }
+    a.out_value[(int64_t)i * N + r] = value; a.out_status[(int64_t)i * N + r] = (uint8_t)rstatus; a.out_fault[(int64_t)i * N + r] = (uint8_t)rfault;
+    if (a.hist_value && pos < a.hist_cap) {
+        const int64_t o = ((int64_t)pos * NSENS + i) * N + r;
+        a.hist_value[o] = value; a.hist_status[o] = (uint8_t)rstatus; a.hist_fault[o] = (uint8_t)rfault;
     }
 }
 
-// group of sensors I0 (and I1 >= 0, read after I0 within a step as in read_all_sensors' dict order) on line LINE
-template <int G, int I0, int I1, int LINE>
-__device__ __forceinline__ void run_group(const SensorArgs &a, int64_t r)
+// read_all_sensors (__main__.py:121-163) for the R reactors of this wavefront after one outer step; called by all
+// 64 lanes.  r_first: ensemble index of the wavefront's first reactor; hist0[s]: reads reactor s had taken before
+// this work item; k: outer steps of the item completed before this one.  Leaves the readings in io.val / io.fault.
+template <class A> __device__ __forceinline__ void suite_step(const A &a, StepIO &io, int64_t r_first, int R, const int *hist0, int k)
 {
-    const int64_t N = a.N;
-    const int steps = a.tap_count[r];
-    if (steps <= 0) return;
-    const float fs = a.full_scale[r];
-    const double t_first = a.time_end[r] - a.t_enable[r] - (double)(steps - 1) * a.dt;   // time of the first read
-    const int hist0 = a.hist_value ? a.hist_pos[(int64_t)G * N + r] : 0;
-    Line ln = {nullptr, nullptr, N, 0, 0};
-    if (LINE >= 0) {
-        ln.rt = a.ring_t + ((int64_t)LINE * RING) * N + r; ln.rv = a.ring_v + ((int64_t)LINE * RING) * N + r;
-        ln.pushes = a.ring_push[(int64_t)LINE * N + r]; ln.cursor = a.ring_cursor[(int64_t)LINE * N + r];
-    }
-    SState s0 = load_state(a, I0, r);
-    SState s1 = load_state(a, I1 >= 0 ? I1 : I0, r);
-    for (int k = 0; k < steps; ++k) {
-        const double t = t_first + (double)k * a.dt;
-        const float *tap = a.taps + ((int64_t)k * NTAP) * N + r;
-        float value; int rstatus, rfault;
-        read_sensor<I0>(s0, ln, tap, N, t, fs, value, rstatus, rfault);
-        emit(a, I0, r, k, steps, hist0, value, rstatus, rfault);
-        if (I1 >= 0) {
-            read_sensor<(I1 >= 0 ? I1 : I0)>(s1, ln, tap, N, t, fs, value, rstatus, rfault);
-            emit(a, I1, r, k, steps, hist0, value, rstatus, rfault);
+    const int lane = threadIdx.x & 63;
+    for (int base = 0; base < NGROUP * R; base += 64) {
+        const int idx = base + lane;
+        const int g = idx / R, sl = idx - g * R;            // sensor group, reactor slot
+        if (g >= NGROUP || !io.stepped[sl]) continue;
+        const int64_t r = r_first + sl, N = a.N;
+        const float fs = a.full_scale[r];
+        const double t = io.t_after[sl] - a.t_enable[r];
+        const int line = (g < 2) ? g : -1;                  // groups 0 / 1 own the inlet / outlet sample line
+        Line ln = {nullptr, nullptr, N, 0, 0};
+        if (line >= 0) {
+            ln.rt = a.ring_t + ((int64_t)line * RING) * N + r; ln.rv = a.ring_v + ((int64_t)line * RING) * N + r;
+            ln.pushes = a.ring_push[(int64_t)line * N + r]; ln.cursor = a.ring_cursor[(int64_t)line * N + r];
         }
-    }
-    store_state(a, I0, r, s0);
-    if (I1 >= 0) store_state(a, I1, r, s1);
-    if (LINE >= 0) { a.ring_push[(int64_t)LINE * N + r] = ln.pushes; a.ring_cursor[(int64_t)LINE * N + r] = ln.cursor; }
-    if (a.hist_value) a.hist_pos[(int64_t)G * N + r] = hist0 + steps;
-}
-
-// grid = (blocks of 64 reactors, NGROUP): one wavefront per (reactor block, sensor group).  Single-wavefront
-// workgroups on purpose: the kernel shares the GPU with physics launches of the other reactor ranges, whose
-// wavefronts each own a whole SIMD's registers, and a one-wave workgroup fits into any SIMD that frees up.
-__global__ __launch_bounds__(64) void sensor_suite_kernel(const SensorArgs a)
-{
-    const int64_t r = a.r0 + (int64_t)blockIdx.x * 64 + threadIdx.x;
-    if (r < a.r1) {
-        switch (blockIdx.y) {                                // wave-uniform
-        case 0: run_group<0, 0, 5, 0>(a, r); break;         // pH_inlet, temp_inlet share the inlet line
-        case 1: run_group<1, 1, 6, 1>(a, r); break;         // pH_outlet, temp_outlet share the outlet line
-        case 2: run_group<2, 2, -1, -1>(a, r); break;       // chlorine_inlet (amperometric)
-        case 3: run_group<3, 3, -1, -1>(a, r); break;       // chlorine_outlet (DPD)
-        default: run_group<4, 4, -1, -1>(a, r); break;      // flow_main (magnetic)
+        const int pos = hist0[sl] + k;
+        // first sensor of the group: pH_inlet, pH_outlet, chlorine_inlet, chlorine_outlet, flow_main; then, on
+        // the same sample line, temp_inlet / temp_outlet (read_all_sensors' dict order)
+        for (int sub = 0; sub < 2; ++sub) {
+            if (sub == 1 && g >= 2) break;
+            const int i = (sub == 0) ? g : 5 + g;
+            SState st = load_state(a, i, r);
+            float value; int rstatus, rfault;
+            read_sensor(i, st, ln, &io.tap[0][sl], t, fs, value, rstatus, rfault);
+            store_state(a, i, r, st);
+            emit(a, i, r, pos, value, rstatus, rfault);
+            io.val[i][sl] = value; io.fault[i][sl] = rfault;
         }
-    }
-    if (!a.plc_on) return;
-    // The wavefront that finishes a reactor block last publishes it: update_modbus_inputs, then
-    // read_modbus_commands + apply_boundary_conditions (__main__.py:411-421).  Release our readings,
-    // count arrivals, and let the last arriver acquire everyone else's before it reads them.
-    __threadfence();
-    int prev = 0;
-    if (threadIdx.x == 0) prev = atomicAdd(a.arrive + a.arrive_base + blockIdx.x, 1);
-    prev = __builtin_amdgcn_readfirstlane(prev);
-    if (prev != NGROUP - 1) return;
-    __threadfence();
-    if (threadIdx.x == 0) a.arrive[a.arrive_base + blockIdx.x] = 0;   // ready for the next launch (stream order)
-    if (r < a.r1) {
-        wtp::pack_inputs(a.pack, r);
-        wtp::apply_commands(a.cmd, r);
+        if (line >= 0) { a.ring_push[(int64_t)line * N + r] = ln.pushes; a.ring_cursor[(int64_t)line * N + r] = ln.cursor; }
     }
 }
 
@@ -418,7 +396,7 @@ __global__ __launch_bounds__(256) void sensor_init_kernel(const SensorInitArgs a
         a.out_value[(int64_t)i * N + r] = __builtin_nanf(""); a.out_status[(int64_t)i * N + r] = ST_NORMAL; a.out_fault[(int64_t)i * N + r] = FL_NONE;
     }
     a.ring_push[r] = 0; a.ring_push[N + r] = 0; a.ring_cursor[r] = 0; a.ring_cursor[N + r] = 0;
-    if (a.hist_pos) for (int g = 0; g < 5; ++g) a.hist_pos[(int64_t)g * N + r] = 0;
+    if (a.hist_pos) a.hist_pos[r] = 0;
 }
 
 } // namespace wts

@@ -2,7 +2,6 @@
 // Owns device memory behind an opaque handle, uploads the SoA constant / boundary
 // blocks, launches the gfx950 kernels of wt_device.hpp on the handle's stream.
 #include "wt_device.hpp"
-#include "wt_sensors.hpp"
 #include "wt_diag.hpp"
 #include "../../include/wtphys.h"
 
@@ -49,15 +48,19 @@ struct wt_ensemble {
     uint32_t *status = nullptr;
     int32_t *stats = nullptr;
     int64_t *wave_diag = nullptr; // optional per-wavefront diagnostics (wt_ensemble_enable_wave_diag)
+    double *bad_T = nullptr;      // [N] temperature named by the reference's ValueError
+    // device-side work queue of the default schedule (wt_device.hpp): control words, FIFO slots, next step per group
+    int32_t *q_ctrl = nullptr; unsigned long long *q_slots = nullptr; int32_t *q_next = nullptr;
+    int q_cap = 0, q_workers = 0;
+    int64_t n_groups = 0;
+    int sched_mode = WT_SCHED_QUEUE;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool have_bc = false, have_state = false;
-    // Launch schedule: the ensemble is cut into n_sub contiguous reactor ranges, each
-    // advanced on its own HIP stream in launches of at most chunk_steps outer steps.
-    // Reactors are independent, so the hardware queues interleave the ranges' wavefronts:
-    // a range whose launch ends in a slow wavefront only delays its own next launch, and
-    // 1250 wavefronts of work no longer take two full rounds on 1024 SIMDs.
+    // Schedule.  WT_SCHED_QUEUE (default): one launch per wt_ensemble_step call, worker wavefronts take
+    // (wavefront-group, next few outer steps) items from a device-side FIFO.  WT_SCHED_STREAMS (round-1
+    // schedule, kept for comparison): n_sub contiguous reactor ranges on their own HIP streams, launches of
+    // at most chunk_steps outer steps.  chunk_steps is also the PLC scan interval.
     int n_sub = 1, chunk_steps = WT_DEFAULT_CHUNK;
-    int sync_outer = 1;
     int step_limit = 2000;    // attempts per outer step before a reactor is given up (reference: unlimited)
     hipStream_t sub_stream[WT_MAX_STREAMS] = {};
     hipEvent_t sub_done[WT_MAX_STREAMS] = {};
@@ -66,14 +69,14 @@ struct wt_ensemble {
     bool sensors_on = false;
     uint64_t sens_seed = 0; int64_t sens_reactor_base = 0;
     float *s_fs = nullptr, *s_full_scale = nullptr, *s_ring_t = nullptr, *s_ring_v = nullptr, *s_out_value = nullptr, *s_hist_value = nullptr;
-    double *s_ds = nullptr, *s_t_enable = nullptr, *s_tap_time = nullptr;
-    int32_t *s_is = nullptr, *s_ring_head = nullptr, *s_ring_cnt = nullptr, *s_hist_pos = nullptr, *s_tap_count = nullptr;
+    double *s_ds = nullptr, *s_t_enable = nullptr;
+    int32_t *s_is = nullptr, *s_ring_head = nullptr, *s_ring_cnt = nullptr, *s_hist_pos = nullptr;
     uint8_t *s_out_status = nullptr, *s_out_fault = nullptr, *s_hist_status = nullptr, *s_hist_fault = nullptr;
-    float *s_taps = nullptr; int s_taps_steps = 0; int s_hist_cap = 0;
-    // optional plant I/O: Modbus register images per reactor (wt_plc.hpp); one PLC scan per launch
+    int s_hist_cap = 0;
+    // optional plant I/O: Modbus register images per reactor (wt_plc.hpp); one PLC scan every chunk_steps outer steps
     bool plc_on = false;
     double *diag_out = nullptr;
-    uint16_t *p_ir = nullptr, *p_hr = nullptr; double *p_loop_time = nullptr; uint8_t *p_update_ok = nullptr; int32_t *p_arrive = nullptr;
+    uint16_t *p_ir = nullptr, *p_hr = nullptr; double *p_loop_time = nullptr; uint8_t *p_update_ok = nullptr;
     // optional per-launch HIP-event timing (bench.py roofline accounting)
     bool time_launches = false;
     std::vector<hipEvent_t> lt_pool;   // start/stop pairs
@@ -82,17 +85,28 @@ struct wt_ensemble {
 
 namespace {
 
-wt::StepArgs make_args(const wt_ensemble *h, double dt, int n_steps)
+wt::StepArgs make_args(const wt_ensemble *h, double dt, int n_steps, int first_step, int call_steps, int scan_every)
 {
     wt::StepArgs a;
     a.N = h->N; a.r0 = 0; a.r1 = h->N; a.n = h->n; a.R = h->R;
     a.par = h->par; a.bc = h->bc;
     a.pH = h->pH; a.Cl = h->Cl; a.T = h->T; a.time = h->time; a.flow = h->flow;
     a.dH = h->dH; a.dRho = h->dRho; a.dK = h->dK;
-    a.status = h->status; a.stats = h->stats; a.wave_diag = h->wave_diag;
-    a.dt = dt; a.n_steps = n_steps; a.sync_outer = h->sync_outer; a.step_limit = h->step_limit;
-    a.taps = h->sensors_on ? h->s_taps : nullptr; a.tap_count = h->sensors_on ? h->s_tap_count : nullptr;
-    a.tap_time = h->sensors_on ? h->s_tap_time : nullptr;
+    a.status = h->status; a.stats = h->stats; a.wave_diag = h->wave_diag; a.bad_T = h->bad_T;
+    a.dt = dt; a.n_steps = n_steps; a.first_step = first_step; a.call_steps = call_steps; a.step_limit = h->step_limit;
+    a.q_ctrl = nullptr; a.q_slots = nullptr; a.q_next = nullptr; a.q_cap = 0; a.item_steps = n_steps; a.n_groups = (int)h->n_groups;
+    wts::SuiteArgs &s = a.sens;
+    memset(&s, 0, sizeof s);
+    s.on = h->sensors_on ? 1 : 0; s.plc_on = h->plc_on ? 1 : 0; s.scan_every = scan_every > 0 ? scan_every : 1;
+    s.N = h->N; s.reactor_base = h->sens_reactor_base;
+    s.seed_lo = (uint32_t)(h->sens_seed & 0xffffffffu); s.seed_hi = (uint32_t)(h->sens_seed >> 32);
+    s.t_enable = h->s_t_enable; s.fs = h->s_fs; s.ds = h->s_ds; s.is = h->s_is; s.full_scale = h->s_full_scale;
+    s.ring_t = h->s_ring_t; s.ring_v = h->s_ring_v; s.ring_push = h->s_ring_head; s.ring_cursor = h->s_ring_cnt;
+    s.out_value = h->s_out_value; s.out_status = h->s_out_status; s.out_fault = h->s_out_fault;
+    s.hist_value = h->s_hist_value; s.hist_status = h->s_hist_status; s.hist_fault = h->s_hist_fault;
+    s.hist_cap = h->s_hist_cap; s.hist_pos = h->s_hist_pos;
+    s.pack.loop_time = h->p_loop_time; s.pack.ir = h->p_ir; s.pack.update_ok = h->p_update_ok;
+    s.cmd.N = h->N; s.cmd.hr = h->p_hr; s.cmd.bc = h->bc;
     return a;
 }
 
@@ -103,14 +117,14 @@ void release_sensor_buffers(wt_ensemble *h)
     free_and_null(h->s_fs); free_and_null(h->s_full_scale); free_and_null(h->s_ring_t); free_and_null(h->s_ring_v);
     free_and_null(h->s_out_value); free_and_null(h->s_hist_value); free_and_null(h->s_ds); free_and_null(h->s_t_enable);
     free_and_null(h->s_is); free_and_null(h->s_ring_head); free_and_null(h->s_ring_cnt); free_and_null(h->s_hist_pos);
-    free_and_null(h->s_tap_count); free_and_null(h->s_tap_time); free_and_null(h->s_out_status); free_and_null(h->s_out_fault);
-    free_and_null(h->s_hist_status); free_and_null(h->s_hist_fault); free_and_null(h->s_taps);
-    h->s_taps_steps = 0; h->s_hist_cap = 0; h->sensors_on = false;
+    free_and_null(h->s_out_status); free_and_null(h->s_out_fault);
+    free_and_null(h->s_hist_status); free_and_null(h->s_hist_fault);
+    h->s_hist_cap = 0; h->sensors_on = false;
 }
 
 void release_plc_buffers(wt_ensemble *h)
 {
-    free_and_null(h->p_ir); free_and_null(h->p_hr); free_and_null(h->p_loop_time); free_and_null(h->p_update_ok); free_and_null(h->p_arrive);
+    free_and_null(h->p_ir); free_and_null(h->p_hr); free_and_null(h->p_loop_time); free_and_null(h->p_update_ok);
     h->plc_on = false;
 }
 
@@ -124,66 +138,66 @@ int default_streams(int64_t n_reactors, int R)
     return ns < 1 ? 1 : (ns > 4 ? 4 : ns);
 }
 
-void launch_step_raw(const wt_ensemble *h, const wt::StepArgs &a, hipStream_t stream);
-
-// the rest of one pass of the reference's loop body after reactor.step, for the reactors of this launch:
-// read_all_sensors and -- with plant I/O on -- update_modbus_inputs, read_modbus_commands +
-// apply_boundary_conditions (__main__.py:398-427), one kernel
-void launch_io(wt_ensemble *h, const wt::StepArgs &a, hipStream_t stream, int slot)
+// the kernel instantiation for this zone count
+template <class F> void with_step_kernel(int n, F &&f)
 {
-    if (!h->sensors_on) return;
-    wts::SensorArgs s;
-    s.N = h->N; s.r0 = a.r0; s.r1 = a.r1; s.reactor_base = h->sens_reactor_base;
-    s.seed_lo = (uint32_t)(h->sens_seed & 0xffffffffu); s.seed_hi = (uint32_t)(h->sens_seed >> 32);
-    s.n_steps = a.n_steps; s.dt = a.dt; s.taps = h->s_taps; s.tap_count = h->s_tap_count; s.time_end = h->s_tap_time; s.t_enable = h->s_t_enable;
-    s.fs = h->s_fs; s.ds = h->s_ds; s.is = h->s_is; s.full_scale = h->s_full_scale;
-    s.ring_t = h->s_ring_t; s.ring_v = h->s_ring_v; s.ring_push = h->s_ring_head; s.ring_cursor = h->s_ring_cnt;
-    s.out_value = h->s_out_value; s.out_status = h->s_out_status; s.out_fault = h->s_out_fault;
-    s.hist_value = h->s_hist_value; s.hist_status = h->s_hist_status; s.hist_fault = h->s_hist_fault;
-    s.hist_cap = h->s_hist_cap; s.hist_pos = h->s_hist_pos;
-    s.plc_on = h->plc_on ? 1 : 0;
-    s.pack.N = h->N; s.pack.value = h->s_out_value; s.pack.fault = h->s_out_fault; s.pack.tap_count = h->s_tap_count;
-    s.pack.loop_time = h->p_loop_time; s.pack.dt = a.dt; s.pack.ir = h->p_ir; s.pack.update_ok = h->p_update_ok;
-    s.cmd.N = h->N; s.cmd.hr = h->p_hr; s.cmd.bc = h->bc;
-    s.arrive = h->p_arrive; s.arrive_base = a.r0 / 64 + slot;   // distinct counters for every block of every range
-    const unsigned grid = (unsigned)((a.r1 - a.r0 + 63) / 64);
-    hipLaunchKernelGGL(wts::sensor_suite_kernel, dim3(grid, wts::NGROUP), dim3(64), 0, stream, s);
-}
-
-void launch_step(wt_ensemble *h, const wt::StepArgs &a, hipStream_t stream, int slot)
-{
-    if (!h->time_launches) { launch_step_raw(h, a, stream); launch_io(h, a, stream, slot); return; }
-    if (h->lt_used + 2 > h->lt_pool.size()) {
-        for (int i = 0; i < 2; ++i) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) { launch_step_raw(h, a, stream); return; } h->lt_pool.push_back(e); }
-    }
-    (void)hipEventRecord(h->lt_pool[h->lt_used], stream);
-    launch_step_raw(h, a, stream);
-    (void)hipEventRecord(h->lt_pool[h->lt_used + 1], stream);
-    h->lt_used += 2;
-    launch_io(h, a, stream, slot);
-}
-
-void launch_step_raw(const wt_ensemble *h, const wt::StepArgs &a, hipStream_t stream)
-{
-    const unsigned grid = (unsigned)((a.r1 - a.r0 + h->R - 1) / h->R);
-    const dim3 g(grid), b(64);
-    const int lv = levels_for(h->n);
-    if (row_mode(h->n)) { // n in {2,4,8,16}: every cross-lane move is a DPP row operation
+#ifdef WT_ONLY_LV3   // scratch builds for kernel tuning: n in 5..8 only (n = 8 takes the row-shift variant)
+    (void)n; f(wt::step_kernel<3, true>);
+#else
+    const int lv = levels_for(n);
+    if (row_mode(n)) { // n in {2,4,8,16}: every cross-lane move is a DPP row operation
         switch (lv) {
-        case 1: hipLaunchKernelGGL((wt::step_kernel<1, true>), g, b, 0, stream, a); break;
-        case 2: hipLaunchKernelGGL((wt::step_kernel<2, true>), g, b, 0, stream, a); break;
-        case 3: hipLaunchKernelGGL((wt::step_kernel<3, true>), g, b, 0, stream, a); break;
-        default: hipLaunchKernelGGL((wt::step_kernel<4, true>), g, b, 0, stream, a); break;
+        case 1: f(wt::step_kernel<1, true>); break;
+        case 2: f(wt::step_kernel<2, true>); break;
+        case 3: f(wt::step_kernel<3, true>); break;
+        default: f(wt::step_kernel<4, true>); break;
         }
     } else {
         switch (lv) {
-        case 2: hipLaunchKernelGGL((wt::step_kernel<2, false>), g, b, 0, stream, a); break;
-        case 3: hipLaunchKernelGGL((wt::step_kernel<3, false>), g, b, 0, stream, a); break;
-        case 4: hipLaunchKernelGGL((wt::step_kernel<4, false>), g, b, 0, stream, a); break;
-        case 5: hipLaunchKernelGGL((wt::step_kernel<5, false>), g, b, 0, stream, a); break;
-        default: hipLaunchKernelGGL((wt::step_kernel<6, false>), g, b, 0, stream, a); break;
+        case 2: f(wt::step_kernel<2, false>); break;
+        case 3: f(wt::step_kernel<3, false>); break;
+        case 4: f(wt::step_kernel<4, false>); break;
+        case 5: f(wt::step_kernel<5, false>); break;
+        default: f(wt::step_kernel<6, false>); break;
         }
     }
+#endif
+}
+
+void launch_step_raw(const wt_ensemble *h, const wt::StepArgs &a, unsigned grid, hipStream_t stream)
+{
+    with_step_kernel(h->n, [&](auto kernel) { hipLaunchKernelGGL(kernel, dim3(grid), dim3(64), 0, stream, a); });
+}
+
+// one kernel launch, bracketed by HIP events on its own stream when launch timing is on
+void launch_step(wt_ensemble *h, const wt::StepArgs &a, unsigned grid, hipStream_t stream)
+{
+    bool timed = h->time_launches;
+    if (timed && h->lt_used + 2 > h->lt_pool.size()) {
+        for (int i = 0; i < 2 && timed; ++i) {
+            hipEvent_t e;
+            if (hipEventCreate(&e) != hipSuccess) timed = false; else h->lt_pool.push_back(e);
+        }
+        if (!timed) while (h->lt_pool.size() > h->lt_used) { (void)hipEventDestroy(h->lt_pool.back()); h->lt_pool.pop_back(); }
+    }
+    if (timed) (void)hipEventRecord(h->lt_pool[h->lt_used], stream);
+    launch_step_raw(h, a, grid, stream);
+    if (timed) { (void)hipEventRecord(h->lt_pool[h->lt_used + 1], stream); h->lt_used += 2; }
+}
+
+// worker wavefronts of the queue schedule: as many as the device keeps resident (no more than there are groups)
+int queue_workers(const wt_ensemble *h)
+{
+    int per_cu = 0, cus = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, h->device) == hipSuccess) cus = prop.multiProcessorCount;
+    with_step_kernel(h->n, [&](auto kernel) {
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 64, 0) != hipSuccess) per_cu = 0;
+    });
+    if (cus <= 0) cus = 256;
+    if (per_cu <= 0) per_cu = 4;
+    const int64_t cap = (int64_t)cus * per_cu;
+    return (int)(h->n_groups < cap ? h->n_groups : cap);
 }
 
 } // namespace
@@ -236,6 +250,13 @@ int wt_ensemble_create(int64_t n_reactors, int n_zones, int device, const double
     ALLOC(h->flow, sizeof(double) * N);
     ALLOC(h->status, sizeof(uint32_t) * N);
     ALLOC(h->stats, sizeof(int32_t) * 5 * N);
+    ALLOC(h->bad_T, sizeof(double) * N);
+    h->n_groups = (n_reactors + h->R - 1) / h->R;
+    if (h->n_groups > 0x3fffffff) { cleanup(); return fail(WT_E_ARG, "too many reactors for one ensemble"); }
+    h->q_cap = (int)(2 * h->n_groups + 64);
+    ALLOC(h->q_ctrl, sizeof(int32_t) * wt::Q_WORDS);
+    ALLOC(h->q_slots, sizeof(unsigned long long) * (size_t)h->q_cap);
+    ALLOC(h->q_next, sizeof(int32_t) * (size_t)h->n_groups);
 #undef ALLOC
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { cleanup(); return fail(WT_E_HIP, "hipStreamCreate failed"); }
     h->own_stream = true;
@@ -243,11 +264,14 @@ int wt_ensemble_create(int64_t n_reactors, int n_zones, int device, const double
     if (hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess) { cleanup(); return fail(WT_E_HIP, "hipEventCreate failed"); }
     h->n_sub = default_streams(n_reactors, h->R);
     h->chunk_steps = WT_DEFAULT_CHUNK;
+    h->sched_mode = WT_SCHED_QUEUE;
+    h->q_workers = queue_workers(h);
     hipError_t e = hipMemcpyAsync(h->par, par, sizeof(double) * WT_NP * N, hipMemcpyHostToDevice, h->stream);
     if (e == hipSuccess) e = hipMemsetAsync(h->status, 0, sizeof(uint32_t) * N, h->stream);
     if (e == hipSuccess) e = hipMemsetAsync(h->stats, 0, sizeof(int32_t) * 5 * N, h->stream);
     if (e == hipSuccess) e = hipMemsetAsync(h->time, 0, sizeof(double) * N, h->stream);
     if (e == hipSuccess) e = hipMemsetAsync(h->flow, 0, sizeof(double) * N, h->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(h->bad_T, 0, sizeof(double) * N, h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     if (e != hipSuccess) { cleanup(); return fail(WT_E_HIP, std::string("upload: ") + hipGetErrorString(e)); }
     *out = h;
@@ -259,15 +283,16 @@ int wt_ensemble_destroy(wt_ensemble *h)
     if (!h) return WT_OK;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    void *ptrs[] = {h->par, h->bc, h->pH, h->Cl, h->T, h->time, h->flow, h->dH, h->dRho, h->dK, h->status, h->stats, h->wave_diag};
+    void *ptrs[] = {h->par, h->bc, h->pH, h->Cl, h->T, h->time, h->flow, h->dH, h->dRho, h->dK, h->status, h->stats, h->wave_diag,
+                    h->bad_T, h->q_ctrl, h->q_slots, h->q_next};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (int s = 0; s < WT_MAX_STREAMS; ++s) {
         if (h->sub_stream[s]) { (void)hipStreamSynchronize(h->sub_stream[s]); (void)hipStreamDestroy(h->sub_stream[s]); }
         if (h->sub_done[s]) (void)hipEventDestroy(h->sub_done[s]);
     }
     void *sp[] = {h->s_fs, h->s_full_scale, h->s_ring_t, h->s_ring_v, h->s_out_value, h->s_hist_value, h->s_ds, h->s_t_enable, h->s_is,
-                  h->s_ring_head, h->s_ring_cnt, h->s_hist_pos, h->s_tap_count, h->s_tap_time, h->s_out_status, h->s_out_fault, h->s_hist_status,
-                  h->s_hist_fault, h->s_taps, h->p_ir, h->p_hr, h->p_loop_time, h->p_update_ok, h->p_arrive, h->diag_out};
+                  h->s_ring_head, h->s_ring_cnt, h->s_hist_pos, h->s_out_status, h->s_out_fault, h->s_hist_status,
+                  h->s_hist_fault, h->p_ir, h->p_hr, h->p_loop_time, h->p_update_ok, h->diag_out};
     for (void *p : sp) if (p) (void)hipFree(p);
     for (hipEvent_t e : h->lt_pool) (void)hipEventDestroy(e);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
@@ -298,18 +323,12 @@ int wt_ensemble_set_state(wt_ensemble *h, const double *pH, const double *Cl, co
     HIP_TRY(hipMemcpyAsync(h->Cl, Cl, sizeof(double) * cnt, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipMemcpyAsync(h->T, T, sizeof(double) * cnt, hipMemcpyHostToDevice, h->stream));
     if (time) HIP_TRY(hipMemcpyAsync(h->time, time, sizeof(double) * h->N, hipMemcpyHostToDevice, h->stream));
-    // ReactorState.update_derived placeholders (reactor.py:137-147)
-    std::vector<double> tmp(cnt);
-    for (size_t i = 0; i < cnt; ++i) tmp[i] = std::pow(10.0, -pH[i]);
-    HIP_TRY(hipMemcpyAsync(h->dH, tmp.data(), sizeof(double) * cnt, hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));
-    std::fill(tmp.begin(), tmp.end(), 998.2);
-    HIP_TRY(hipMemcpyAsync(h->dRho, tmp.data(), sizeof(double) * cnt, hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));
-    std::fill(tmp.begin(), tmp.end(), 0.0001);
-    HIP_TRY(hipMemcpyAsync(h->dK, tmp.data(), sizeof(double) * cnt, hipMemcpyHostToDevice, h->stream));
+    // ReactorState.update_derived placeholders (reactor.py:137-147), filled where the state now lives
+    wt::PlaceholderArgs pa{(int64_t)cnt, h->pH, h->dH, h->dRho, h->dK};
+    hipLaunchKernelGGL(wt::derived_placeholder_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, h->stream, pa);
+    HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemsetAsync(h->status, 0, sizeof(uint32_t) * h->N, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));   // the caller's buffers are free on return
     h->have_state = true;
     return WT_OK;
 }
@@ -332,21 +351,32 @@ int wt_ensemble_step(wt_ensemble *h, double dt, int n_steps, int fused)
     if (n_steps < 0) return fail(WT_E_ARG, "n_steps must be >= 0");
     if (n_steps == 0) return WT_OK;
     HIP_TRY(hipSetDevice(h->device));
+    // chunk_steps: PLC scan interval; under the stream schedule also the launch length
     const int chunk = fused ? (h->chunk_steps > 0 ? h->chunk_steps : n_steps) : 1;
-    if (h->sensors_on) {   // tap buffer for the longest launch of this call
-        const int need = chunk < n_steps ? chunk : n_steps;
-        if (need > h->s_taps_steps) {
-            HIP_TRY(hipStreamSynchronize(h->stream));
-            if (h->s_taps) (void)hipFree(h->s_taps);
-            h->s_taps = nullptr;
-            HIP_TRY(hipMalloc((void **)&h->s_taps, sizeof(float) * (size_t)need * 7 * (size_t)h->N));
-            h->s_taps_steps = need;
-        }
+    if (h->wave_diag)
+        HIP_TRY(hipMemsetAsync(h->wave_diag, 0, sizeof(int64_t) * wt::WT_DIAG_SLOTS * (size_t)h->n_groups, h->stream));
+    if (h->sched_mode == WT_SCHED_QUEUE) {
+        // One launch.  Item length: short enough that every worker handles a few dozen items (the last items of a
+        // launch cannot be balanced), never longer than a scan interval needs to be, at most 32 steps.
+        const int W = h->q_workers > 0 ? h->q_workers : 1;
+        int64_t item = ((int64_t)n_steps * h->n_groups) / ((int64_t)W * 24);
+        if (item > 32) item = 32;
+        if (item < 1) item = 1;
+        wt::StepArgs a = make_args(h, dt, n_steps, 0, n_steps, chunk);
+        a.q_ctrl = h->q_ctrl; a.q_slots = h->q_slots; a.q_next = h->q_next; a.q_cap = h->q_cap; a.item_steps = (int)item;
+        HIP_TRY(hipMemsetAsync(h->q_ctrl, 0, sizeof(int32_t) * wt::Q_WORDS, h->stream));
+        HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)(h->q_ctrl + wt::Q_AVAIL), (int)h->n_groups, 1, h->stream));
+        HIP_TRY(hipMemsetAsync(h->q_slots, 0, sizeof(unsigned long long) * (size_t)h->q_cap, h->stream));
+        HIP_TRY(hipMemsetAsync(h->q_next, 0, sizeof(int32_t) * (size_t)h->n_groups, h->stream));
+        launch_step(h, a, (unsigned)W, h->stream);
+        HIP_TRY(hipGetLastError());
+        return WT_OK;
     }
     const int S = h->n_sub;
     if (S <= 1) {
         for (int done = 0; done < n_steps; done += chunk) {
-            launch_step(h, make_args(h, dt, (n_steps - done < chunk) ? n_steps - done : chunk), h->stream, 0);
+            const wt::StepArgs a = make_args(h, dt, (n_steps - done < chunk) ? n_steps - done : chunk, done, n_steps, chunk);
+            launch_step(h, a, (unsigned)h->n_groups, h->stream);
         }
         HIP_TRY(hipGetLastError());
         return WT_OK;
@@ -360,13 +390,13 @@ int wt_ensemble_step(wt_ensemble *h, double dt, int n_steps, int fused)
     // fork: every range's stream waits for what is already queued on the handle's stream
     HIP_TRY(hipEventRecord(h->ev_fork, h->stream));
     for (int s = 0; s < S; ++s) HIP_TRY(hipStreamWaitEvent(h->sub_stream[s], h->ev_fork, 0));
-    const int64_t groups = (h->N + h->R - 1) / h->R;   // wavefront-sized groups of reactors
+    const int64_t groups = h->n_groups;   // wavefront-sized groups of reactors
     for (int done = 0; done < n_steps; done += chunk) {
-        wt::StepArgs a = make_args(h, dt, (n_steps - done < chunk) ? n_steps - done : chunk);
+        wt::StepArgs a = make_args(h, dt, (n_steps - done < chunk) ? n_steps - done : chunk, done, n_steps, chunk);
         for (int s = 0; s < S; ++s) {
             const int64_t g0 = groups * s / S, g1 = groups * (s + 1) / S;
             a.r0 = g0 * h->R; a.r1 = (g1 * h->R < h->N) ? g1 * h->R : h->N;
-            if (a.r1 > a.r0) launch_step(h, a, h->sub_stream[s], s);
+            if (a.r1 > a.r0) launch_step(h, a, (unsigned)(g1 - g0), h->sub_stream[s]);
         }
     }
     HIP_TRY(hipGetLastError());
@@ -426,15 +456,13 @@ int wt_ensemble_sensors_enable(wt_ensemble *h, uint64_t seed, int64_t reactor_ba
     SALLOC(h->s_out_value, sizeof(float) * wts::NSENS * N);
     SALLOC(h->s_out_status, wts::NSENS * N);
     SALLOC(h->s_out_fault, wts::NSENS * N);
-    SALLOC(h->s_tap_count, sizeof(int32_t) * N);
     SALLOC(h->s_t_enable, sizeof(double) * N);
-    SALLOC(h->s_tap_time, sizeof(double) * N);
     h->s_hist_cap = history_capacity;
     if (history_capacity > 0) {
         SALLOC(h->s_hist_value, sizeof(float) * (size_t)history_capacity * wts::NSENS * N);
         SALLOC(h->s_hist_status, (size_t)history_capacity * wts::NSENS * N);
         SALLOC(h->s_hist_fault, (size_t)history_capacity * wts::NSENS * N);
-        SALLOC(h->s_hist_pos, sizeof(int32_t) * wts::NGROUP * N);
+        SALLOC(h->s_hist_pos, sizeof(int32_t) * N);
     }
 #undef SALLOC
     hipError_t e = hipMemcpy(cfg, cfg_flow, sizeof(double) * N, hipMemcpyHostToDevice);
@@ -443,7 +471,6 @@ int wt_ensemble_sensors_enable(wt_ensemble *h, uint64_t seed, int64_t reactor_ba
     if (e == hipSuccess) e = hipMemcpyAsync(h->s_t_enable, h->time, sizeof(double) * N, hipMemcpyDeviceToDevice, h->stream);
     if (e == hipSuccess) e = hipMemsetAsync(h->s_ring_t, 0, sizeof(float) * 2 * wts::RING * N, h->stream);
     if (e == hipSuccess) e = hipMemsetAsync(h->s_ring_v, 0, sizeof(float) * 2 * wts::RING * N, h->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(h->s_tap_count, 0, sizeof(int32_t) * N, h->stream);
     if (e == hipSuccess) {
         wts::SensorInitArgs a;
         a.N = h->N; a.cfg_flow = cfg; a.cfg_cl = cfg + N; a.cfg_temp = cfg + 2 * N;
@@ -495,18 +522,15 @@ int wt_ensemble_plc_enable(wt_ensemble *h)
     if (h->plc_on) return fail(WT_E_STATE, "plant I/O already enabled");
     HIP_TRY(hipSetDevice(h->device));
     const size_t N = (size_t)h->N;
-    const size_t n_arrive = N / 64 + WT_MAX_STREAMS + 2;
     hipError_t e = hipMalloc((void **)&h->p_ir, sizeof(uint16_t) * wtp::IR_WORDS * N);
     if (e == hipSuccess) e = hipMalloc((void **)&h->p_hr, sizeof(uint16_t) * wtp::HR_WORDS * N);
     if (e == hipSuccess) e = hipMalloc((void **)&h->p_loop_time, sizeof(double) * N);
     if (e == hipSuccess) e = hipMalloc((void **)&h->p_update_ok, N);
-    if (e == hipSuccess) e = hipMalloc((void **)&h->p_arrive, sizeof(int32_t) * n_arrive);
     // ModbusSequentialDataBlock(0, [0] * size): every register starts at 0 (slave.py:134-137); sim_time = 0.0
     if (e == hipSuccess) e = hipMemsetAsync(h->p_ir, 0, sizeof(uint16_t) * wtp::IR_WORDS * N, h->stream);
     if (e == hipSuccess) e = hipMemsetAsync(h->p_hr, 0, sizeof(uint16_t) * wtp::HR_WORDS * N, h->stream);
     if (e == hipSuccess) e = hipMemsetAsync(h->p_loop_time, 0, sizeof(double) * N, h->stream);
     if (e == hipSuccess) e = hipMemsetAsync(h->p_update_ok, 1, N, h->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(h->p_arrive, 0, sizeof(int32_t) * n_arrive, h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     if (e != hipSuccess) { release_plc_buffers(h); return fail(WT_E_HIP, std::string("plc_enable: ") + hipGetErrorString(e)); }
     h->plc_on = true;
@@ -583,7 +607,7 @@ int wt_ensemble_set_step_limit(wt_ensemble *h, int max_attempts)
 int wt_ensemble_set_sync(wt_ensemble *h, int sync_outer)
 {
     if (!h) return fail(WT_E_ARG, "NULL handle");
-    h->sync_outer = sync_outer ? 1 : 0;
+    (void)sync_outer;   // the reactors of a wavefront always start an outer step together (see include/wtphys.h)
     return WT_OK;
 }
 
@@ -591,7 +615,8 @@ int wt_ensemble_set_schedule(wt_ensemble *h, int n_streams, int chunk_steps)
 {
     if (!h) return fail(WT_E_ARG, "NULL handle");
     if (n_streams < 0 || n_streams > WT_MAX_STREAMS) return fail(WT_E_ARG, "n_streams out of range");
-    if (chunk_steps < 0) return fail(WT_E_ARG, "chunk_steps must be >= 0 (0 = whole call in one launch)");
+    if (chunk_steps < 0) return fail(WT_E_ARG, "chunk_steps must be >= 0 (0 = one scan / launch per call)");
+    h->sched_mode = n_streams > 0 ? WT_SCHED_STREAMS : WT_SCHED_QUEUE;
     h->n_sub = n_streams > 0 ? n_streams : default_streams(h->N, h->R);
     h->chunk_steps = chunk_steps;
     return WT_OK;
@@ -600,10 +625,30 @@ int wt_ensemble_set_schedule(wt_ensemble *h, int n_streams, int chunk_steps)
 int wt_ensemble_get_schedule(wt_ensemble *h, int *mode, int *n_streams, int *chunk_steps, int *workers)
 {
     if (!h) return fail(WT_E_ARG, "NULL handle");
-    if (mode) *mode = WT_SCHED_STREAMS;
-    if (n_streams) *n_streams = h->n_sub;
+    if (mode) *mode = h->sched_mode;
+    if (n_streams) *n_streams = h->sched_mode == WT_SCHED_STREAMS ? h->n_sub : 0;
     if (chunk_steps) *chunk_steps = h->chunk_steps;
-    if (workers) *workers = 0;
+    if (workers) *workers = h->sched_mode == WT_SCHED_QUEUE ? h->q_workers : 0;
+    return WT_OK;
+}
+
+int wt_ensemble_queue_error(wt_ensemble *h, int *error)
+{
+    if (!h || !error) return fail(WT_E_ARG, "NULL argument");
+    HIP_TRY(hipSetDevice(h->device));
+    int32_t w[wt::Q_WORDS];
+    HIP_TRY(hipMemcpyAsync(w, h->q_ctrl, sizeof w, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    *error = w[wt::Q_ERROR];
+    return WT_OK;
+}
+
+int wt_ensemble_get_bad_temperature(wt_ensemble *h, double *value)
+{
+    if (!h || !value) return fail(WT_E_ARG, "NULL argument");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipMemcpyAsync(value, h->bad_T, sizeof(double) * h->N, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
     return WT_OK;
 }
 
@@ -612,6 +657,10 @@ int wt_ensemble_synchronize(wt_ensemble *h)
     if (!h) return fail(WT_E_ARG, "NULL handle");
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipStreamSynchronize(h->stream));
+    int qerr = 0;
+    const int rc = wt_ensemble_queue_error(h, &qerr);
+    if (rc != WT_OK) return rc;
+    if (qerr) return fail(WT_E_HIP, "work queue hand-off timed out inside the step kernel; the state is incomplete");
     return WT_OK;
 }
 
@@ -767,7 +816,7 @@ int wt_ensemble_wave_diag(wt_ensemble *h, int64_t *out, int64_t capacity, int64_
 {
     if (!h || !n_waves) return fail(WT_E_ARG, "NULL argument");
     HIP_TRY(hipSetDevice(h->device));
-    const int64_t nw = (h->N + h->R - 1) / h->R;
+    const int64_t nw = h->n_groups;
     *n_waves = nw;
     if (!h->wave_diag) {   // first call switches the diagnostics on
         HIP_TRY(hipMalloc((void **)&h->wave_diag, sizeof(int64_t) * wt::WT_DIAG_SLOTS * (size_t)nw));

@@ -61,7 +61,9 @@ enum {
     WT_ST_CLAMP_T = 16,       /* reactor.py:539-541 */
     WT_ST_T_RANGE_POST = 32,  /* ValueError out of _update_derived_state (reactor.py:522-524):
                                  state/time/H/density were updated, decay rate and clamps were not */
-    WT_ST_NONFINITE = 64,
+    WT_ST_NONFINITE = 64,     /* the state is not finite at the start of a step: scipy's solve_ivp raises ValueError
+                                 ("All components of the initial state `y0` must be finite."), self.state untouched;
+                                 the reactor does not advance until the host rewrites its state */
     WT_ST_STEP_LIMIT = 128    /* not a reference behaviour: the attempt limit of wt_ensemble_set_step_limit was hit;
                                  always together with WT_ST_SOLVER_FAILED, state = last accepted y */
 };
@@ -95,24 +97,28 @@ int wt_ensemble_set_state(wt_ensemble *h, const double *pH, const double *Cl, co
 /* BoundaryConditions for every reactor (reactor.py:150-186), host [WT_NB][N]. */
 int wt_ensemble_set_boundary(wt_ensemble *h, const double *bc);
 
-/* IntegratedCSTR.step(dt, boundary) n_steps times (reactor.py:450-509), boundary
- * held constant; asynchronous, ordered after and before other work on the
- * handle's stream.  fused != 0 keeps the state in registers across up to
- * chunk_steps outer steps per launch; fused == 0 launches one kernel per outer
- * step.  Results do not depend on the schedule (tests assert bitwise equality). */
+/* IntegratedCSTR.step(dt, boundary) n_steps times (reactor.py:450-509); asynchronous, ordered after and
+ * before other work on the handle's stream.  The boundary is held constant unless plant I/O is on (then the
+ * command path rewrites it at every PLC scan).  fused == 0 makes every outer step a PLC scan, as the reference's
+ * loop does; otherwise a scan happens every chunk_steps outer steps and at the end of the call.  Results do not
+ * depend on the schedule (tests assert bitwise equality). */
 int wt_ensemble_step(wt_ensemble *h, double dt, int n_steps, int fused);
-/* Launch schedule: the ensemble is advanced as n_streams contiguous reactor ranges
- * on internal HIP streams (fork/join around the handle's stream), at most
- * chunk_steps outer steps per launch (0 = the whole call in one launch).
- * Default: min(4, wavefronts/64) ranges, WT_DEFAULT_CHUNK steps. */
+/* Schedule.  n_streams == 0 (default), WT_SCHED_QUEUE: one kernel launch per call; worker wavefronts take
+ * (wavefront-group, next few outer steps) work items from a device-side FIFO, so no wavefront ever waits for a
+ * launch boundary and a scan per outer step costs no launch.  n_streams >= 1, WT_SCHED_STREAMS (the round-1
+ * schedule, kept for comparison): n_streams contiguous reactor ranges on internal HIP streams (fork/join around
+ * the handle's stream), launches of at most chunk_steps outer steps.  chunk_steps is the PLC scan interval under
+ * both (0 = one scan per call).  Default: queue, WT_DEFAULT_CHUNK. */
 int wt_ensemble_set_schedule(wt_ensemble *h, int n_streams, int chunk_steps);
-/* the schedule in force: mode (WT_SCHED_*), reactor ranges / streams, outer steps per launch or work
- * item, and worker wavefronts of the persistent schedule (0 under WT_SCHED_STREAMS) */
+/* the schedule in force: mode (WT_SCHED_*), reactor ranges / streams (0 under WT_SCHED_QUEUE), scan interval,
+ * worker wavefronts of the queue schedule (0 under WT_SCHED_STREAMS) */
 enum { WT_SCHED_STREAMS = 0, WT_SCHED_QUEUE = 1 };
 int wt_ensemble_get_schedule(wt_ensemble *h, int *mode, int *n_streams, int *chunk_steps, int *workers);
-/* sync_outer != 0: the reactors sharing a wavefront start every outer step together (they wait
- * for the slowest of them) so that their Jacobian / factorisation / Newton work coincides.
- * Results are unaffected; it is a throughput knob. */
+/* != 0 after a launch whose work-queue hand-off gave up waiting (never observed; wt_ensemble_synchronize reports it) */
+int wt_ensemble_queue_error(wt_ensemble *h, int *error);
+/* Kept for ABI compatibility, no effect: the reactors sharing a wavefront always start an outer step
+ * together (they wait for the slowest of them), which is what makes the end of an outer step a
+ * wavefront-uniform point for the sensor suite and the PLC scan.  Results never depended on it. */
 int wt_ensemble_set_sync(wt_ensemble *h, int sync_outer);
 /* Guard the reference lacks.  Where the solution slides along a discontinuity of the RHS (the
  * 8 degC density branch, spatial.py:177-189, under strong heat loss) scipy's Radau takes millions
@@ -130,6 +136,9 @@ int wt_ensemble_get_state(wt_ensemble *h, double *pH, double *Cl, double *T, dou
 /* H_concentration, density, chlorine_decay_rate (reactor.py:511-524), [N][n] each. */
 int wt_ensemble_get_derived(wt_ensemble *h, double *H, double *rho, double *kdecay);
 int wt_ensemble_get_status(wt_ensemble *h, uint32_t *flags /* [N] */);
+/* the temperature the reference's ValueError names (thermodynamics.py:151: the first out-of-range zone of the
+ * evaluation that raised) for reactors flagged WT_ST_T_RANGE / WT_ST_T_RANGE_POST; [N], undefined elsewhere */
+int wt_ensemble_get_bad_temperature(wt_ensemble *h, double *value /* [N] */);
 int wt_ensemble_clear_status(wt_ensemble *h);
 int wt_ensemble_get_stats(wt_ensemble *h, wt_solver_stats *stats /* [N] */);
 

@@ -175,10 +175,11 @@ def g4():
         try:
             s = r.step(1.0, b)
             hist.append([s.pH.tolist(), s.chlorine.tolist(), s.temperature.tolist()])
-        except ValueError:
+        except ValueError as e:
             idx = k
+            msg = str(e)
             break
-    out["cold_run"] = {"config": cfg_to_dict(cfg), "bc": bc_to_vec(b), "raise_step_index": idx,
+    out["cold_run"] = {"config": cfg_to_dict(cfg), "bc": bc_to_vec(b), "raise_step_index": idx, "message": msg,
                        "state_before_raise": hist[-1], "time_before_raise": r.state.time}
     try:
         IntegratedCSTR(ReactorConfiguration(flow_rate=0.0))

@@ -56,9 +56,10 @@ def test_suite_statistics_and_independence(gpu, wt):
         out = ens.sensor_readings(); st = ens.state
         ens.close()
         return out, st
-    (v, s, f), st = run(1, 0)
-    (v2, s2, f2), _ = run(4, 7)
-    assert np.array_equal(v, v2, equal_nan=True) and np.array_equal(s, s2) and np.array_equal(f, f2)
+    (v, s, f), st = run(0, 50)            # work-queue schedule (default)
+    for sched in ((1, 0), (4, 7), (0, 1)):
+        (v2, s2, f2), _ = run(*sched)
+        assert np.array_equal(v, v2, equal_nan=True) and np.array_equal(s, s2) and np.array_equal(f, f2), sched
     (v3, s3, f3), _ = run(2, 25, base=1000, sl=slice(1000, 1500))
     assert np.array_equal(v[:, 1000:1500], v3, equal_nan=True) and np.array_equal(s[:, 1000:1500], s3)
     # at t = 400 s: flow (10 s), RTD (30 s), DPD (60 s), amperometric (300 s) are warm, pH (1800 s) is not
@@ -86,3 +87,35 @@ def test_suite_statistics_and_independence(gpu, wt):
     assert abs(np.mean(z)) < 5e-4 and 0.002 < np.std(z) < 0.006
     # distinct reactors draw distinct noise
     assert np.unique(np.round(resid, 6)).size > 0.95 * resid.size
+
+
+def test_suite_at_config5_share_vs_oracle(gpu, wt):
+    """BASELINE config 5's per-GPU share (12 500 reactors x 8 zones, sensors on): the readings of a sample of
+    reactors over 45 steps against the sensor oracle fed the device's own per-step state; every wavefront position
+    (first / last reactor of a wavefront, last wavefront of the ensemble) is in the sample."""
+    import sensor_oracle as SO
+    N, n, steps, seed = 12500, 8, 45, 0xC0FFEE
+    cols, bc = wt.make_ensemble(N)
+    ens = wt.ReactorEnsemble(cols, n_zones=n); ens.set_boundary(bc)
+    ens.enable_sensors(seed=seed, reactor_base=0, history=steps)
+    sample = [0, 7, 8, 63, 64, 4099, 9999, 12488, 12495, 12496, 12499]
+    suites = {r: SO.SensorSuite(float(cols["flow_rate"][r]), float(cols["initial_chlorine"][r]), float(cols["temperature"][r]),
+                                0.0, seed, r) for r in sample}
+    ov = np.empty((steps, 7, len(sample))); os_ = np.empty((steps, 7, len(sample)), dtype=np.uint8); of = np.empty_like(os_)
+    f32 = lambda x: float(np.float32(x))
+    for k in range(steps):
+        es = ens.step(1.0, n_steps=1)
+        for j, r in enumerate(sample):
+            v, s, f = suites[r].read_all({0: f32(es.pH[r, 0]), -1: f32(es.pH[r, -1])}, {0: f32(es.chlorine[r, 0]), -1: f32(es.chlorine[r, -1])},
+                                         {0: f32(es.temperature[r, 0]), -1: f32(es.temperature[r, -1])}, f32(es.flow_rate[r]), float(es.time[r]))
+            ov[k, :, j], os_[k, :, j], of[k, :, j] = v, s, f
+    hv, hs, hf, nf = ens.sensor_history()
+    assert np.all(nf == steps)
+    hv, hs, hf = hv[:, :, sample], hs[:, :, sample], hf[:, :, sample]
+    assert np.array_equal(np.isnan(hv), np.isnan(ov))
+    ok = ~np.isnan(ov)
+    assert ok.sum() > 500 and np.max(np.abs(hv[ok] - ov[ok]) / (1.0 + np.abs(ov[ok]))) < 2e-5      # fp32 signal path
+    assert np.array_equal(hs, os_) and np.array_equal(hf, of)
+    v, s, f = ens.sensor_readings()
+    assert np.array_equal(v[:, sample], hv[-1], equal_nan=True)
+    ens.close()

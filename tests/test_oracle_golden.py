@@ -235,3 +235,44 @@ def test_nonfinite_state_raises_like_reference(wt, oracle):
         y, t, der, status = oracle.step(4, par, bc, 1.0, y0, 1.0)
         assert status == oracle.ST_NONFINITE and t == 1.0 == nf["nan"]["time_after"]
         assert np.array_equal(y, y0, equal_nan=True)
+
+
+def outlier_errors(wt, oracle, n, linsolve=0):
+    """Worst relative error per g10 reactor of the CPU oracle against 100 steps of the reference."""
+    g = golden_npz(f"g10_outliers_n{n}.npz")
+    R, every, steps = g["reactors"], int(g["every"]), int(g["steps"])
+    cols, bc = wt.make_ensemble(int(R.max()) + 1)
+    d = wt.ReactorConfiguration()
+    full = {k: np.broadcast_to(np.asarray(cols.get(k, getattr(d, k))), (int(R.max()) + 1,)).copy()
+            for k in ("volume", "height", "diameter", "flow_rate", "impeller_speed", "impeller_diameter",
+                      "total_carbonate", "temperature", "enable_thermal_stratification", "alkalinity")}
+    par = np.ascontiguousarray(wt.params.derive_constants(full, n)[:, R]); b = np.ascontiguousarray(bc[:, R])
+    S = len(R)
+    A = [np.broadcast_to(cols[k][R][:, None], (S, n)).copy() for k in ("initial_pH", "initial_chlorine", "temperature")] + [np.zeros(S)]
+    worst = np.zeros(S)
+    oracle.set_linsolve(linsolve)
+    try:
+        for k in range(steps // every):
+            A = list(oracle.ensemble_step(n, par, b, 1.0, every, *A, nthreads=8))
+            assert not A[4].any()
+            A = A[:4]
+            snap = g["snaps"][:, k]
+            worst = np.maximum(worst, np.stack([np.abs(A[i] - snap[:, i]) / np.abs(snap[:, i]) for i in range(3)]).max(axis=(0, 2)))
+    finally:
+        oracle.set_linsolve(0)
+    return worst
+
+
+@pytest.mark.parametrize("n", [4, 8, 20])
+def test_outlier_reactors_oracle_vs_reference(wt, oracle, n):
+    """g10: the reactors of the bench ensembles on which GPU and oracle differ by more than 1e-7, 100 steps of the
+    reference itself.  Even the bit-faithful oracle (same algorithm, dense LU as scipy; it differs from the
+    reference by libm-vs-numpy-SIMD last bits of pow/exp only) leaves the 1e-6 band on some of them, and so does
+    its tridiagonal variant: on these reactors the solve crosses stratification switches of the RHS with repeated
+    rejections, and two correct executions agree to the solver's own tolerance (rtol 1e-6 per internal step) only.
+    Observed here: n = 4 max 7.7e-9; n = 8 max 6.0e-7 / 1.4e-6 (dense / tridiagonal); n = 20 max 4.0e-6 / 1.7e-6."""
+    e0, e1 = outlier_errors(wt, oracle, n, 0), outlier_errors(wt, oracle, n, 1)
+    bound = {4: 1e-7, 8: 5e-6, 20: 2e-5}[n]
+    assert e0.max() < bound and e1.max() < bound
+    if n == 20:      # the phenomenon is a property of the algorithm on these inputs, not of one implementation
+        assert (e0 > 1e-6).sum() >= 3 and (e1 > 1e-6).sum() >= 3
