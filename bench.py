@@ -202,8 +202,11 @@ def run_rank(args) -> int:
         args.sensors = True
 
     waves = -(-N // (64 // n))
-    if args.chunk <= 0:      # stream schedule: a launch lasts as long as its slowest wavefront, keep >= 4 launches per range
-        args.chunk = min(DEFAULT_CHUNK, max(1, -(-args.steps // (4 if args.steps > 50 else 2))))
+    if args.chunk <= 0:
+        if args.streams > 0:  # stream schedule: a launch lasts as long as its slowest wavefront, keep >= 4 launches per range
+            args.chunk = min(DEFAULT_CHUNK, max(1, -(-args.steps // (4 if args.steps > 50 else 2))))
+        else:                 # queue schedule: the chunk is only the PLC scan interval
+            args.chunk = DEFAULT_CHUNK
     ens = None
     if not dry:
         ens = wt.ReactorEnsemble(cols, n_zones=n, device=local_rank)

@@ -108,7 +108,7 @@ struct StepArgs {
     int q_cap, item_steps, n_groups;
     wts::SuiteArgs sens; // fused sensor suite + plant I/O (sens.on == 0: none)
 };
-enum { Q_AVAIL = 0, Q_HEAD = 1, Q_TAIL = 2, Q_ERROR = 3, Q_WORDS = 16 };
+enum { Q_AVAIL = 0, Q_HEAD = 1, Q_TAIL = 2, Q_ERROR = 3, Q_ITEMS = 4, Q_TICKS = 5, Q_WORDS = 16 };   // Q_TICKS: 100 MHz ticks / 16
 
 // ---------------------------------------------------------------- lane geometry and cross-lane moves
 struct Lane {
@@ -218,7 +218,7 @@ struct RK {
     // chemistry.py:116-132 constants (frozen at configuration temperature)
     double Kw, Ka1, Ka1Ka2, KaH, cbeta;
     // transport / spatial: Richardson number (g drho dz) / (rho_avg u^2) against Ri_crit (spatial.py:262-277,293)
-    double Kex, dz, u2, ricrit, supp;
+    double Kex, dz, u2, ricrit, rihulp, supp;   // rihulp: half an ulp of Ri_crit
     int strat_mode; // 0: stratification off, 1: Richardson test, 2: u<=1e-6 (Ri=+inf)
     // boundary-derived (reactor.py:336,349-368,385-395,426-443)
     double Qv, H_in, Cl_in, T_in, acid_dH, cl_dose, UAr, T_amb;
@@ -233,6 +233,8 @@ struct RK {
     double dose0;     // chlorine dosing in zone 0 (0 elsewhere / when off)
     double UAr_on;    // heat-loss coefficient (0 when off)
 };
+
+__device__ __forceinline__ double ulp_above_pos(double t) { return __longlong_as_double(__double_as_longlong(t) + 1) - t; }
 
 // cmd != nullptr: boundary rows 0 / 4 / 6 (inlet, acid, chlorine flow) as the command path has just set them
 __device__ __forceinline__ void load_reactor(const double *par, const double *bc, int64_t N, int64_t r, int n, RK &k,
@@ -253,6 +255,7 @@ __device__ __forceinline__ void load_reactor(const double *par, const double *bc
     k.dz = height / n;                          // spatial.py:119
     k.u2 = u * u;                               // velocity_scale ** 2
     k.ricrit = P(11);
+    k.rihulp = 0.5 * ulp_above_pos(k.ricrit);
     k.supp = P(12);
     k.strat_mode = (P(10) != 0.0) ? ((u > 1e-6) ? 1 : 2) : 0; // reactor.py:310, spatial.py:270-275
     const double Q_in = B(0);
@@ -287,13 +290,13 @@ __device__ __forceinline__ void mask_reactor_for_lane(const Lane &L, RK &k)
 // estimate) they would occupy 38 VGPRs of a register file that is already oversubscribed, so they are parked
 // in LDS and fetched at the top of every RHS block: 14 per-reactor words (one copy per reactor, broadcast to
 // its lanes) and 5 per-lane ones.
-constexpr int RK_UNI = 16, RK_LANE = 5, RK_MAXR = 32;   // up to 32 reactors per wavefront (n = 2)
+constexpr int RK_UNI = 17, RK_LANE = 5, RK_MAXR = 32;   // up to 32 reactors per wavefront (n = 2)
 struct RKStore { double *uni; double *lane; };          // uni[c * RK_MAXR], lane[c * 64]: already offset for this lane
 
 __device__ __forceinline__ void park_reactor(const RKStore &st, const RK &k)
 {
     const double u[RK_UNI] = {k.Kw, k.Ka1, k.Ka1Ka2, k.KaH, k.cbeta, k.dz, k.u2, k.supp, k.H_in, k.Cl_in, k.T_in, k.T_amb, k.UAr_on,
-                              (double)k.strat_mode, k.ricrit, k.flowsum};
+                              (double)k.strat_mode, k.ricrit, k.flowsum, k.rihulp};
     const double l[RK_LANE] = {k.Kex_hi, k.Qv_in, k.Qv_out, k.acid0, k.dose0};
 #pragma unroll
     for (int c = 0; c < RK_UNI; ++c) st.uni[c * RK_MAXR] = u[c];     // every lane of the reactor stores the same value
@@ -307,7 +310,7 @@ __device__ __forceinline__ RK fetch_reactor(const RKStore &st)
     k.Kw = st.uni[0 * RK_MAXR]; k.Ka1 = st.uni[1 * RK_MAXR]; k.Ka1Ka2 = st.uni[2 * RK_MAXR]; k.KaH = st.uni[3 * RK_MAXR];
     k.cbeta = st.uni[4 * RK_MAXR]; k.dz = st.uni[5 * RK_MAXR]; k.u2 = st.uni[6 * RK_MAXR]; k.supp = st.uni[7 * RK_MAXR];
     k.H_in = st.uni[8 * RK_MAXR]; k.Cl_in = st.uni[9 * RK_MAXR]; k.T_in = st.uni[10 * RK_MAXR]; k.T_amb = st.uni[11 * RK_MAXR];
-    k.UAr_on = st.uni[12 * RK_MAXR]; k.strat_mode = (int)st.uni[13 * RK_MAXR]; k.ricrit = st.uni[14 * RK_MAXR];
+    k.UAr_on = st.uni[12 * RK_MAXR]; k.strat_mode = (int)st.uni[13 * RK_MAXR]; k.ricrit = st.uni[14 * RK_MAXR]; k.rihulp = st.uni[16 * RK_MAXR];
     k.Kex_hi = st.lane[0 * 64]; k.Qv_in = st.lane[1 * 64]; k.Qv_out = st.lane[2 * 64]; k.acid0 = st.lane[3 * 64]; k.dose0 = st.lane[4 * 64];
     return k;
 }
@@ -369,19 +372,18 @@ __device__ __forceinline__ void rhs_rows(const Lane &L, const RK &k, double H, d
                                          double rho, double Cl, double T, double f[3])
 {
 #pragma clang fp contract(off)
-    // mixing suppression of the interface above this zone (spatial.py:239-320): Ri = (g drho dz) / (rho_avg u^2)
-    // > Ri_crit, in the reference's operation order.  The reciprocal product decides unless it lands within
-    // a few ulp of the threshold; only then is the correctly rounded quotient the reference compares formed.
+    // mixing suppression of the interface above this zone (spatial.py:239-320): the reference compares the
+    // correctly rounded quotient Ri = num / den, num = (g drho) dz, den = rho_avg u^2 > 0, with Ri_crit.
+    // fl(num / den) > c  <=>  num / den > c + ulp(c)/2  <=>  num - c den > (ulp(c)/2) den, and the left side is
+    // exact in one fma whenever the two sides are close enough for rounding to matter: the same decision as the
+    // reference's on the same bits, without a division.
     const double rho_hi = from_hi<ROW, 1>(L, rho);
     double s = 1.0;
     if (k.strat_mode == 1) {
         const double drho = rho_hi - rho;
         const double ravg = 0.5 * (rho + rho_hi);
         const double num = (9.81 * drho) * k.dz, den = ravg * k.u2;
-        const double q = num * rcp(den);
-        bool stable = q > k.ricrit;
-        if (fabs(q - k.ricrit) <= 1e-13 * k.ricrit) stable = __ddiv_rn(num, den) > k.ricrit;
-        if (stable) s = k.supp;
+        if (__builtin_fma(-k.ricrit, den, num) > k.rihulp * den) s = k.supp;
     } else if (k.strat_mode == 2) {
         s = k.supp;
     }
@@ -392,12 +394,12 @@ __device__ __forceinline__ void rhs_rows(const Lane &L, const RK &k, double H, d
     const double H_lo = keep_m(L.m_lo[0], from_lo<ROW, 1>(L, H)), H_hi = keep_m(L.m_hi[0], from_hi<ROW, 1>(L, H));
     const double C_lo = keep_m(L.m_lo[0], from_lo<ROW, 1>(L, Cl)), C_hi = keep_m(L.m_hi[0], from_hi<ROW, 1>(L, Cl));
     const double T_lo = keep_m(L.m_lo[0], from_lo<ROW, 1>(L, T)), T_hi = keep_m(L.m_hi[0], from_hi<ROW, 1>(L, T));
-    // K @ x the way OpenBLAS' dgemv accumulates it inside the reference: neighbours first, diagonal last, each
-    // product fused into the running sum.  k_lo / k_hi are exactly 0 where there is no neighbour, and what
-    // was read there is finite (keep_m).
-    const double mixH = __builtin_fma(kd, H, __builtin_fma(k_hi, H_hi, k_lo * H_lo));
-    const double mixC = __builtin_fma(kd, Cl, __builtin_fma(k_hi, C_hi, k_lo * C_lo));
-    const double mixT = __builtin_fma(kd, T, __builtin_fma(k_hi, T_hi, k_lo * T_lo));
+    // K @ x the way OpenBLAS' dgemv accumulates it inside the reference: neighbours first, diagonal last, every
+    // product rounded before it is added (pinned by tests/golden/g2_rhs_*.npz: temperature rows bit-identical).
+    // k_lo / k_hi are exactly 0 where there is no neighbour, and what was read there is finite (keep_m).
+    const double mixH = (k_lo * H_lo + k_hi * H_hi) + kd * H;
+    const double mixC = (k_lo * C_lo + k_hi * C_hi) + kd * Cl;
+    const double mixT = (k_lo * T_lo + k_hi * T_hi) + kd * T;
 
     // zone-0 dosing and inlet (reactor.py:349-368,388-395,420) through pre-masked coefficients;
     // iw is 0 when the reference's `beta > 0` guard fails
@@ -925,22 +927,33 @@ __device__ __forceinline__ void queue_push(const StepArgs &a, int group)
     __hip_atomic_fetch_add(a.q_ctrl + Q_AVAIL, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// Next group for this worker, or -1 to retire.  own >= 0: the group just advanced still has steps to go -- it goes to
-// the back of the queue if another group is waiting (fair rotation: with more groups than resident wavefronts every
-// group advances at the same rate and nobody idles), otherwise this worker simply carries on with it.
-__device__ __forceinline__ int queue_next(const StepArgs &a, int own)
+// Next group for this worker, or -1 to retire.  own >= 0: the group just advanced still has steps to go.  It goes
+// to the back of the queue if another group is waiting (fair rotation: with more groups than resident wavefronts
+// every group advances at the same rate and nobody idles) -- unless `hold`: a group whose items take clearly longer
+// than the ensemble's average is on the launch's critical path and keeps its worker.  Only an exchange hands data
+// to another CU, so only then the wavefront releases what it wrote (and the taker acquires).
+__device__ __forceinline__ int queue_next(const StepArgs &a, int own, bool hold, bool &exchanged)
 {
-    int next = -1;
-    if ((threadIdx.x & 63) == 0) {
+    const bool lane0 = (threadIdx.x & 63) == 0;
+    int ticket = -1;
+    if (lane0 && !(own >= 0 && hold)) {
         const int old = __hip_atomic_fetch_add(a.q_ctrl + Q_AVAIL, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (old > 0) {
-            const int t = __hip_atomic_fetch_add(a.q_ctrl + Q_HEAD, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (own >= 0) queue_push(a, own);
-            next = queue_resolve(a, t);
-        } else {
-            __hip_atomic_fetch_add(a.q_ctrl + Q_AVAIL, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            next = own;
-        }
+        if (old > 0) ticket = __hip_atomic_fetch_add(a.q_ctrl + Q_HEAD, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else __hip_atomic_fetch_add(a.q_ctrl + Q_AVAIL, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    ticket = __builtin_amdgcn_readfirstlane(ticket);
+    exchanged = ticket >= 0;
+    if (ticket < 0) return own;                 // nothing waiting (or holding on): carry on with the own group, or retire
+    if (own >= 0) {
+        // publish the group's state before anybody can take its next item
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    int next = -1;
+    if (lane0) {
+        if (own >= 0) queue_push(a, own);
+        next = queue_resolve(a, ticket);
     }
     return __builtin_amdgcn_readfirstlane(next);
 }
@@ -991,6 +1004,12 @@ __device__ __forceinline__ void run_item(ArgPtr pa, const Lane &L, double *lds, 
     int steps_done = 0;
     SolverCounters last_cnt = {0, 0, 0, 0, 0};
     long long diag_trips = 0, diag_newton = 0, diag_fact = 0, diag_jac = 0, diag_f3 = 0;
+#ifdef WT_STAMPS  // diagnostic build only: shader-clock shares of the loop's sections (never in the product .so)
+    long long sec[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long tprev = __builtin_amdgcn_s_memtime();
+#define WT_STAMP(i) do { const long long tn_ = __builtin_amdgcn_s_memtime(); sec[i] += tn_ - tprev; tprev = tn_; } while (0)
+#else
+#define WT_STAMP(i) do { } while (0)
+#endif
     const long long clk0 = want_diag ? __builtin_amdgcn_s_memtime() : 0, wall0 = want_diag ? __builtin_amdgcn_s_memrealtime() : 0;
     if (present) {
         st = a->status[r];
@@ -1097,6 +1116,7 @@ __device__ __forceinline__ void run_item(ArgPtr pa, const Lane &L, double *lds, 
                 phase = PH_INIT_STEP;
             }
 
+            WT_STAMP(0);   // item / outer-step set-up
             while (true) {
                 // reactors that finished their outer step wait here until every reactor of the wavefront has
                 if (__ballot(phase != PH_DONE) == 0ull) break;
@@ -1157,11 +1177,13 @@ __device__ __forceinline__ void run_item(ArgPtr pa, const Lane &L, double *lds, 
                         phase = PH_NEWTON;
                     }
                 }
+                WT_STAMP(1);   // step / attempt prologues
                 if (__ballot(phase == PH_NEWTON && !have_lu) != 0ull) diag_fact++;
                 if (phase == PH_NEWTON && !have_lu) {
                     factorize<ROW, LV>(L, J, h, F); have_lu = true; cnt_s.nlu += 2;      // radau.py:454-456
                 }
 
+                WT_STAMP(2);   // factorisation
                 // ================= this trip's evaluation points
                 const bool newton = (phase == PH_NEWTON);
                 diag_trips++; if (__ballot(newton) != 0ull) diag_newton++;
@@ -1219,6 +1241,7 @@ __device__ __forceinline__ void run_item(ArgPtr pa, const Lane &L, double *lds, 
                     if (seg_any(L, bad)) { raised = true; phase = PH_DONE; }
                 }
 
+                WT_STAMP(3);   // RHS evaluations
                 // ================= per-phase epilogues
                 if (phase == PH_OUTER_BEGIN) {
 #pragma unroll
@@ -1336,6 +1359,7 @@ __device__ __forceinline__ void run_item(ArgPtr pa, const Lane &L, double *lds, 
                     phase = ((t - t_bound) < 0) ? PH_STEP_BEGIN : PH_DONE;
                 }
 
+                WT_STAMP(4);   // epilogues (Newton solve, error estimate, accept / reject)
                 // ================= finite-difference Jacobian at (yc, f) when a phase asked for it
                 if (__ballot(need_jac) != 0ull) diag_jac++;
                 if (need_jac) {
@@ -1350,6 +1374,7 @@ __device__ __forceinline__ void run_item(ArgPtr pa, const Lane &L, double *lds, 
                         bad |= jbad; raised = true; phase = PH_DONE;
                     }
                 }
+                WT_STAMP(5);   // num_jac
             }
             last_cnt = cnt_s;
 
@@ -1396,6 +1421,7 @@ __device__ __forceinline__ void run_item(ArgPtr pa, const Lane &L, double *lds, 
           }
         }
 
+        WT_STAMP(6);       // post-step (derived, clamps)
         // ================= what follows reactor.step() in the reference's loop body (__main__.py:403-423)
         if (sens_on) {
             ArgPtr b = fresh(pa);            // ---- section: sensors and plant I/O
@@ -1438,6 +1464,7 @@ __device__ __forceinline__ void run_item(ArgPtr pa, const Lane &L, double *lds, 
             }
             __syncthreads();                 // hand-off read; the next step's factors may overwrite it
         }
+        WT_STAMP(7);       // sensor suite, plant I/O
     }
 
     // ================= the item's results
@@ -1469,6 +1496,9 @@ __device__ __forceinline__ void run_item(ArgPtr pa, const Lane &L, double *lds, 
         atomicAdd(o + 3, (unsigned long long)(__builtin_amdgcn_s_memrealtime() - wall0));
         atomicAdd(o + 4, (unsigned long long)diag_fact); atomicAdd(o + 5, (unsigned long long)diag_jac);
         atomicAdd(o + 6, (unsigned long long)diag_f3); atomicAdd(o + 7, 1ull);
+#ifdef WT_STAMPS
+        for (int i = 0; i < 8; ++i) atomicAdd(o + 8 + i, (unsigned long long)sec[i]);
+#endif
     }
 }
 
@@ -1484,27 +1514,38 @@ __global__ __launch_bounds__(64) void step_kernel(const StepArgs a)
     lane_geometry(a.n, L);
     // the by-value argument block sits at offset 0 of the kernel-argument segment
     const ArgPtr pa = (ArgPtr)__builtin_amdgcn_kernarg_segment_ptr();
-    if (!a.q_ctrl) {
-        run_item<LV, ROW>(pa, L, lds, (int)(a.r0 / a.R) + (int)blockIdx.x, 0, a.n_steps);
-        return;
-    }
-    int group = queue_next(a, -1);
-    while (group >= 0) {
-        // the previous worker's release (queue_push) -> this acquire -> plain loads of the group's state
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        int step0 = 0;
-        if ((threadIdx.x & 63) == 0) step0 = __hip_atomic_load(a.q_next + group, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        step0 = __builtin_amdgcn_readfirstlane(step0);
-        const int left = a.n_steps - step0;
-        const int cnt = left < a.item_steps ? left : a.item_steps;
+    const bool queue = a.q_ctrl != nullptr;
+    bool exchanged = true;
+    int group = queue ? queue_next(a, -1, false, exchanged) : (int)(a.r0 / a.R) + (int)blockIdx.x;
+    long long my_ticks = 0; int my_items = 0;   // this group's items while it stays with this worker
+    while (group >= 0) {          // (one call site: the item body exists once in the code object)
+        int step0 = 0, cnt = a.n_steps;
+        long long t0 = 0;
+        if (queue) {
+            // taken over from another worker: its release (queue_next) -> this acquire -> plain loads of the group's state
+            if (exchanged) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); my_ticks = 0; my_items = 0; }
+            if ((threadIdx.x & 63) == 0) step0 = __hip_atomic_load(a.q_next + group, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            step0 = __builtin_amdgcn_readfirstlane(step0);
+            const int left = a.n_steps - step0;
+            cnt = left < a.item_steps ? left : a.item_steps;
+            t0 = __builtin_amdgcn_s_memrealtime();
+        }
         run_item<LV, ROW>(pa, L, lds, group, step0, cnt);
+        if (!queue) break;
         const bool more = step0 + cnt < a.n_steps;
-        // publish the group's state before anybody can take its next item
-        if ((threadIdx.x & 63) == 0) __hip_atomic_store(a.q_next + group, step0 + cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        group = queue_next(a, more ? group : -1);
+        // how long a step of this group takes against the ensemble's average so far (100 MHz ticks)
+        const long long ticks = (__builtin_amdgcn_s_memrealtime() - t0) / cnt;
+        my_ticks += ticks; my_items++;
+        bool hold = false;
+        if ((threadIdx.x & 63) == 0) {
+            __hip_atomic_store(a.q_next + group, step0 + cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int items = __hip_atomic_fetch_add(a.q_ctrl + Q_ITEMS, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+            const int sum = __hip_atomic_fetch_add(a.q_ctrl + Q_TICKS, (int)(ticks >> 4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + (int)(ticks >> 4);
+            // mine / my_items > 1.15 * (16 sum / items)
+            hold = (double)my_ticks * (double)items > 1.15 * 16.0 * (double)sum * (double)my_items;
+        }
+        hold = __builtin_amdgcn_readfirstlane((int)hold) != 0;
+        group = queue_next(a, more ? group : -1, hold, exchanged);
     }
 }
 

@@ -356,10 +356,11 @@ int wt_ensemble_step(wt_ensemble *h, double dt, int n_steps, int fused)
     if (h->wave_diag)
         HIP_TRY(hipMemsetAsync(h->wave_diag, 0, sizeof(int64_t) * wt::WT_DIAG_SLOTS * (size_t)h->n_groups, h->stream));
     if (h->sched_mode == WT_SCHED_QUEUE) {
-        // One launch.  Item length: short enough that every worker handles a few dozen items (the last items of a
-        // launch cannot be balanced), never longer than a scan interval needs to be, at most 32 steps.
+        // One launch.  Item length: a group changes hands at item boundaries, which costs a few microseconds
+        // (state out and in, release / acquire), so not every step -- but often enough that the groups sharing
+        // the workers take turns at least half a dozen times; at most 32 steps.
         const int W = h->q_workers > 0 ? h->q_workers : 1;
-        int64_t item = ((int64_t)n_steps * h->n_groups) / ((int64_t)W * 24);
+        int64_t item = n_steps / 6;
         if (item > 32) item = 32;
         if (item < 1) item = 1;
         wt::StepArgs a = make_args(h, dt, n_steps, 0, n_steps, chunk);
