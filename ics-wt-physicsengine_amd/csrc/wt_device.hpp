@@ -106,9 +106,10 @@ struct StepArgs {
     // q_ctrl: Q_AVAIL, Q_HEAD, Q_TAIL, Q_ERROR; q_slots[q_cap]: (ticket + 1) << 32 | group; q_next[group]: next step.
     int32_t *q_ctrl; unsigned long long *q_slots; int32_t *q_next;
     int q_cap, item_steps, n_groups;
+    int64_t *trace; int trace_cap;   // optional item trace (tools/): worker, group, step0 | cnt << 32, start, end (100 MHz ticks)
     wts::SuiteArgs sens; // fused sensor suite + plant I/O (sens.on == 0: none)
 };
-enum { Q_AVAIL = 0, Q_HEAD = 1, Q_TAIL = 2, Q_ERROR = 3, Q_ITEMS = 4, Q_TICKS = 5, Q_WORDS = 16 };   // Q_TICKS: 100 MHz ticks / 16
+enum { Q_AVAIL = 0, Q_HEAD = 1, Q_TAIL = 2, Q_ERROR = 3, Q_TRACE = 4, Q_WORDS = 16 };
 
 // ---------------------------------------------------------------- lane geometry and cross-lane moves
 struct Lane {
@@ -927,23 +928,25 @@ __device__ __forceinline__ void queue_push(const StepArgs &a, int group)
     __hip_atomic_fetch_add(a.q_ctrl + Q_AVAIL, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// Next group for this worker, or -1 to retire.  own >= 0: the group just advanced still has steps to go.  It goes
-// to the back of the queue if another group is waiting (fair rotation: with more groups than resident wavefronts
-// every group advances at the same rate and nobody idles) -- unless `hold`: a group whose items take clearly longer
-// than the ensemble's average is on the launch's critical path and keeps its worker.  Only an exchange hands data
-// to another CU, so only then the wavefront releases what it wrote (and the taker acquires).
-__device__ __forceinline__ int queue_next(const StepArgs &a, int own, bool hold, bool &exchanged)
+// Next group for this worker, or -1 to retire.  own >= 0: the group just advanced still has steps to go; it goes to
+// the back of the queue if another group is waiting (fair rotation: with more groups than resident wavefronts every
+// group advances at the same rate and nobody idles), otherwise this worker simply carries on with it.  Only an
+// exchange hands data to another CU, so only then the wavefront releases what it wrote (and the taker acquires).
+// (Tried and dropped: letting groups whose items run long keep their worker, and dealing last launch's slow groups
+// first -- a group's cost comes in bursts when a reactor crosses a stratification switch, not as a persistent rate,
+// so neither shortens the tail of a short launch; see DESIGN.md.)
+__device__ __forceinline__ int queue_next(const StepArgs &a, int own, bool &exchanged)
 {
     const bool lane0 = (threadIdx.x & 63) == 0;
     int ticket = -1;
-    if (lane0 && !(own >= 0 && hold)) {
+    if (lane0) {
         const int old = __hip_atomic_fetch_add(a.q_ctrl + Q_AVAIL, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (old > 0) ticket = __hip_atomic_fetch_add(a.q_ctrl + Q_HEAD, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         else __hip_atomic_fetch_add(a.q_ctrl + Q_AVAIL, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     ticket = __builtin_amdgcn_readfirstlane(ticket);
     exchanged = ticket >= 0;
-    if (ticket < 0) return own;                 // nothing waiting (or holding on): carry on with the own group, or retire
+    if (ticket < 0) return own;                 // nothing waiting: carry on with the own group, or retire
     if (own >= 0) {
         // publish the group's state before anybody can take its next item
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1502,6 +1505,16 @@ __device__ __forceinline__ void run_item(ArgPtr pa, const Lane &L, double *lds, 
     }
 }
 
+// Start of a queue-schedule launch: every group is ready for step 0, nothing has been pushed yet.
+struct QueueResetArgs { int32_t *q_ctrl; unsigned long long *q_slots; int32_t *q_next; int n_groups, q_cap; };
+__global__ __launch_bounds__(256) void queue_reset_kernel(const QueueResetArgs a)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < a.q_cap) a.q_slots[i] = 0ull;
+    if (i < a.n_groups) a.q_next[i] = 0;
+    if (i < Q_WORDS) a.q_ctrl[i] = (i == Q_AVAIL) ? a.n_groups : 0;
+}
+
 // The physics kernel.  Queue schedule: a grid of worker wavefronts that take (wavefront-group, next few outer
 // steps) items from a device-side FIFO until the whole ensemble has advanced n_steps -- one launch, no launch
 // tails: a slow wavefront delays nobody, and with more groups than resident wavefronts every SIMD stays busy.
@@ -1516,36 +1529,33 @@ __global__ __launch_bounds__(64) void step_kernel(const StepArgs a)
     const ArgPtr pa = (ArgPtr)__builtin_amdgcn_kernarg_segment_ptr();
     const bool queue = a.q_ctrl != nullptr;
     bool exchanged = true;
-    int group = queue ? queue_next(a, -1, false, exchanged) : (int)(a.r0 / a.R) + (int)blockIdx.x;
-    long long my_ticks = 0; int my_items = 0;   // this group's items while it stays with this worker
+    int group = queue ? queue_next(a, -1, exchanged) : (int)(a.r0 / a.R) + (int)blockIdx.x;
     while (group >= 0) {          // (one call site: the item body exists once in the code object)
         int step0 = 0, cnt = a.n_steps;
         long long t0 = 0;
         if (queue) {
             // taken over from another worker: its release (queue_next) -> this acquire -> plain loads of the group's state
-            if (exchanged) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); my_ticks = 0; my_items = 0; }
+            if (exchanged) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             if ((threadIdx.x & 63) == 0) step0 = __hip_atomic_load(a.q_next + group, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             step0 = __builtin_amdgcn_readfirstlane(step0);
             const int left = a.n_steps - step0;
             cnt = left < a.item_steps ? left : a.item_steps;
-            t0 = __builtin_amdgcn_s_memrealtime();
+            if (a.trace) t0 = __builtin_amdgcn_s_memrealtime();
         }
         run_item<LV, ROW>(pa, L, lds, group, step0, cnt);
         if (!queue) break;
         const bool more = step0 + cnt < a.n_steps;
-        // how long a step of this group takes against the ensemble's average so far (100 MHz ticks)
-        const long long ticks = (__builtin_amdgcn_s_memrealtime() - t0) / cnt;
-        my_ticks += ticks; my_items++;
-        bool hold = false;
         if ((threadIdx.x & 63) == 0) {
             __hip_atomic_store(a.q_next + group, step0 + cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const int items = __hip_atomic_fetch_add(a.q_ctrl + Q_ITEMS, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
-            const int sum = __hip_atomic_fetch_add(a.q_ctrl + Q_TICKS, (int)(ticks >> 4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + (int)(ticks >> 4);
-            // mine / my_items > 1.15 * (16 sum / items)
-            hold = (double)my_ticks * (double)items > 1.15 * 16.0 * (double)sum * (double)my_items;
+            if (a.trace) {
+                const int slot = __hip_atomic_fetch_add(a.q_ctrl + Q_TRACE, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (slot < a.trace_cap) {
+                    int64_t *o = a.trace + (int64_t)slot * 5;
+                    o[0] = blockIdx.x; o[1] = group; o[2] = (int64_t)step0 | ((int64_t)cnt << 32); o[3] = t0; o[4] = __builtin_amdgcn_s_memrealtime();
+                }
+            }
         }
-        hold = __builtin_amdgcn_readfirstlane((int)hold) != 0;
-        group = queue_next(a, more ? group : -1, hold, exchanged);
+        group = queue_next(a, more ? group : -1, exchanged);
     }
 }
 

@@ -7,6 +7,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -54,6 +55,7 @@ struct wt_ensemble {
     int q_cap = 0, q_workers = 0;
     int64_t n_groups = 0;
     int sched_mode = WT_SCHED_QUEUE;
+    int64_t *trace = nullptr; int trace_cap = 0;   // developer item trace (wt_ensemble_item_trace)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool have_bc = false, have_state = false;
     // Schedule.  WT_SCHED_QUEUE (default): one launch per wt_ensemble_step call, worker wavefronts take
@@ -95,6 +97,7 @@ wt::StepArgs make_args(const wt_ensemble *h, double dt, int n_steps, int first_s
     a.status = h->status; a.stats = h->stats; a.wave_diag = h->wave_diag; a.bad_T = h->bad_T;
     a.dt = dt; a.n_steps = n_steps; a.first_step = first_step; a.call_steps = call_steps; a.step_limit = h->step_limit;
     a.q_ctrl = nullptr; a.q_slots = nullptr; a.q_next = nullptr; a.q_cap = 0; a.item_steps = n_steps; a.n_groups = (int)h->n_groups;
+    a.trace = h->trace; a.trace_cap = h->trace_cap;
     wts::SuiteArgs &s = a.sens;
     memset(&s, 0, sizeof s);
     s.on = h->sensors_on ? 1 : 0; s.plc_on = h->plc_on ? 1 : 0; s.scan_every = scan_every > 0 ? scan_every : 1;
@@ -272,6 +275,7 @@ int wt_ensemble_create(int64_t n_reactors, int n_zones, int device, const double
     if (e == hipSuccess) e = hipMemsetAsync(h->time, 0, sizeof(double) * N, h->stream);
     if (e == hipSuccess) e = hipMemsetAsync(h->flow, 0, sizeof(double) * N, h->stream);
     if (e == hipSuccess) e = hipMemsetAsync(h->bad_T, 0, sizeof(double) * N, h->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(h->q_ctrl, 0, sizeof(int32_t) * wt::Q_WORDS, h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     if (e != hipSuccess) { cleanup(); return fail(WT_E_HIP, std::string("upload: ") + hipGetErrorString(e)); }
     *out = h;
@@ -283,6 +287,7 @@ int wt_ensemble_destroy(wt_ensemble *h)
     if (!h) return WT_OK;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->trace) (void)hipFree(h->trace);
     void *ptrs[] = {h->par, h->bc, h->pH, h->Cl, h->T, h->time, h->flow, h->dH, h->dRho, h->dK, h->status, h->stats, h->wave_diag,
                     h->bad_T, h->q_ctrl, h->q_slots, h->q_next};
     for (void *p : ptrs) if (p) (void)hipFree(p);
@@ -363,12 +368,13 @@ int wt_ensemble_step(wt_ensemble *h, double dt, int n_steps, int fused)
         int64_t item = n_steps / 6;
         if (item > 32) item = 32;
         if (item < 1) item = 1;
+        if (const char *e = getenv("WT_Q_ITEM")) item = atoi(e) > 0 ? atoi(e) : item;          // tuning knob (tools/)
         wt::StepArgs a = make_args(h, dt, n_steps, 0, n_steps, chunk);
         a.q_ctrl = h->q_ctrl; a.q_slots = h->q_slots; a.q_next = h->q_next; a.q_cap = h->q_cap; a.item_steps = (int)item;
-        HIP_TRY(hipMemsetAsync(h->q_ctrl, 0, sizeof(int32_t) * wt::Q_WORDS, h->stream));
-        HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)(h->q_ctrl + wt::Q_AVAIL), (int)h->n_groups, 1, h->stream));
-        HIP_TRY(hipMemsetAsync(h->q_slots, 0, sizeof(unsigned long long) * (size_t)h->q_cap, h->stream));
-        HIP_TRY(hipMemsetAsync(h->q_next, 0, sizeof(int32_t) * (size_t)h->n_groups, h->stream));
+        {
+            wt::QueueResetArgs qr{h->q_ctrl, h->q_slots, h->q_next, (int)h->n_groups, h->q_cap};
+            hipLaunchKernelGGL(wt::queue_reset_kernel, dim3((unsigned)((h->q_cap + 255) / 256)), dim3(256), 0, h->stream, qr);
+        }
         launch_step(h, a, (unsigned)W, h->stream);
         HIP_TRY(hipGetLastError());
         return WT_OK;
@@ -641,6 +647,28 @@ int wt_ensemble_queue_error(wt_ensemble *h, int *error)
     HIP_TRY(hipMemcpyAsync(w, h->q_ctrl, sizeof w, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     *error = w[wt::Q_ERROR];
+    return WT_OK;
+}
+
+int wt_ensemble_item_trace(wt_ensemble *h, int64_t *out, int capacity, int *n_items)
+{
+    if (!h || !n_items) return fail(WT_E_ARG, "NULL argument");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (!h->trace) {     // first call switches tracing on
+        if (capacity <= 0) return fail(WT_E_ARG, "capacity must be positive");
+        HIP_TRY(hipMalloc((void **)&h->trace, sizeof(int64_t) * 5 * (size_t)capacity));
+        h->trace_cap = capacity; *n_items = 0;
+        return WT_OK;
+    }
+    int32_t w[wt::Q_WORDS];
+    HIP_TRY(hipMemcpy(w, h->q_ctrl, sizeof w, hipMemcpyDeviceToHost));
+    const int n = w[wt::Q_TRACE] < h->trace_cap ? w[wt::Q_TRACE] : h->trace_cap;
+    *n_items = n;
+    if (out && n > 0) {
+        if (capacity < n) return fail(WT_E_ARG, "trace buffer too small");
+        HIP_TRY(hipMemcpy(out, h->trace, sizeof(int64_t) * 5 * (size_t)n, hipMemcpyDeviceToHost));
+    }
     return WT_OK;
 }
 

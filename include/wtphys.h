@@ -236,6 +236,9 @@ int wt_selftest_shuffles(int device, int n_zones, int *mismatches);
  * [n_waves][wt_wave_diag_slots()] int64 into `out` (8 slots; 16 in -DWT_STAMPS diagnostic builds,
  * which add the shader-clock shares of the kernel loop's sections). */
 int wt_wave_diag_slots(void);
+/* Developer trace of the LAST launch's work items under the queue schedule: {worker, group, first step | steps << 32,
+ * start, end} in 100 MHz ticks, 5 int64 per item.  The first call allocates `capacity` items and switches tracing on. */
+int wt_ensemble_item_trace(wt_ensemble *h, int64_t *out, int capacity, int *n_items);
 int wt_ensemble_wave_diag(wt_ensemble *h, int64_t *out, int64_t capacity, int64_t *n_waves);
 
 int64_t wt_ensemble_size(const wt_ensemble *h);
