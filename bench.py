@@ -129,8 +129,8 @@ def cpu_baseline(ens_constants, cols, bc, n_zones: int, sample_reactors: int, sa
     cores = max(1, min(cores, 64))
     S = sample_reactors
     v_all, dt_all = timed(S, sample_steps, cores)
-    S1 = max(64, min(S, S // max(1, cores // 2)))          # about the same wall time on one core
-    steps1 = max(20, sample_steps // 4)
+    S1 = max(64, min(S, 1024))                              # ~10 s on one core
+    steps1 = max(20, sample_steps // 2)
     v_one, dt_one = timed(S1, steps1, 1)
     return {
         "value": v_all,
@@ -143,6 +143,23 @@ def cpu_baseline(ens_constants, cols, bc, n_zones: int, sample_reactors: int, sa
                      "sample": f"first {S1} reactors, {steps1} steps after {warm_steps} warm-up steps, {dt_one:.2f} s wall"},
         "reference_python": REFERENCE_PYTHON,
     }
+
+
+def dropin_latency(wt, device: int, steps: int = 600):
+    """BASELINE config 1's shape on the GPU drop-in: one 4-zone IntegratedCSTR, dt = 1 s, `steps` calls of
+    step() with the default boundary, host round trip included (state download every step, as the reference's
+    callers see it).  The reference needs 2.64 ms per step on one CPU core."""
+    r = wt.IntegratedCSTR(wt.ReactorConfiguration(n_zones=4), device=device)
+    b = wt.BoundaryConditions()
+    for _ in range(20):
+        r.step(1.0, b)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        r.step(1.0, b)
+    ms = (time.perf_counter() - t0) * 1e3 / steps
+    return {"ms_per_step": ms, "steps": steps, "zones": 4, "reference_python_ms_per_step": 2.64,
+            "note": "IntegratedCSTR.step() of one reactor incl. launch, synchronisation and state download; "
+                    "reference figure: BASELINE.md section 2 (survey container, 1 core)"}
 
 
 def _profile_json(name: str):
@@ -359,6 +376,7 @@ def run_rank(args) -> int:
                                         "one read per outer step, Philox4x32-10 streams",
                                "readings_per_s": total * 7 * args.steps / elapsed} if args.sensors else None)
             if not args.no_cpu_baseline and world == 1:
+                out["dropin_n1"] = dropin_latency(wt, local_rank)
                 out["cpu_baseline"] = cpu_baseline(ens.constants, cols, bc, n, min(args.cpu_sample_reactors, N),
                                                    args.cpu_sample_steps, warm_steps=5)
             elif not args.no_cpu_baseline:

@@ -83,6 +83,8 @@ def lib():
     L.wt_ensemble_synchronize.argtypes = [vp]
     L.wt_ensemble_get_state.argtypes = [vp, dp, dp, dp, dp, dp]
     L.wt_ensemble_get_derived.argtypes = [vp, dp, dp, dp]
+    L.wt_ensemble_get_snapshot.argtypes = [vp, dp, dp, dp, dp, dp, dp, dp, dp, u32p]
+    L.wt_ensemble_get_snapshot.restype = C.c_int
     L.wt_ensemble_get_status.argtypes = [vp, u32p]
     L.wt_ensemble_get_bad_temperature.argtypes = [vp, dp]
     L.wt_ensemble_get_bad_temperature.restype = C.c_int

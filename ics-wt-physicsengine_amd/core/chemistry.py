@@ -62,6 +62,54 @@ class AqueousChemistry:
         buffer_system.validate()
         self.buffer = buffer_system
         self.device = device
+        # chemistry.py:116-132: equilibrium constants frozen at the buffer's temperature (the same
+        # values params.derive_constants uploads as the reactor's constants)
+        from .physics import TemperatureDependentKinetics
+        self.thermo = TemperatureDependentKinetics()
+        T = buffer_system.temperature
+        self.Kw = self.thermo.water_ionization_constant(T)
+        self.pKw = -np.log10(self.Kw)
+        self.pKa1 = self.thermo.carbonate_pKa(T, dissociation=1)
+        self.Ka1 = 10 ** (-self.pKa1)
+        self.pKa2 = self.thermo.carbonate_pKa(T, dissociation=2)
+        self.Ka2 = 10 ** (-self.pKa2)
+        self.pKa_HOCl = 7.5 + 0.01 * (T - 25.0)
+        self.Ka_HOCl = 10 ** (-self.pKa_HOCl)
+
+    # scalar closed forms of one reactor's chemistry (diagnostics, validators); inside step() the same
+    # expressions run per zone per RHS evaluation in the kernel (wt_device.hpp prop_pH)
+    def H_from_pH(self, pH: float) -> float:
+        return 10 ** (-pH)
+
+    def pH_from_H(self, H: float) -> float:
+        return -np.log10(H)
+
+    def alpha_carbonate(self, pH: float):
+        """chemistry.py:158-191."""
+        H = self.H_from_pH(pH)
+        D = H ** 2 + self.Ka1 * H + self.Ka1 * self.Ka2
+        return H ** 2 / D, (self.Ka1 * H) / D, (self.Ka1 * self.Ka2) / D
+
+    def buffering_capacity(self, pH: float) -> float:
+        """chemistry.py:400-437."""
+        H = self.H_from_pH(pH)
+        beta_water = 2.303 * (H + self.Kw / H)
+        C_T_mol = self.buffer.total_carbonate / 1000.0
+        a0, a1, a2 = self.alpha_carbonate(pH)
+        return beta_water + 2.303 * C_T_mol * (a0 * a1 + 4 * a1 * a2 + a0 * a2)
+
+    def chlorine_speciation(self, total_chlorine_mg_L: float, pH: float):
+        """chemistry.py:439-481."""
+        H = self.H_from_pH(pH)
+        a_HOCl = H / (H + self.Ka_HOCl)
+        a_OCl = self.Ka_HOCl / (H + self.Ka_HOCl)
+        return {"HOCl": a_HOCl * total_chlorine_mg_L, "OCl": a_OCl * total_chlorine_mg_L, "HOCl_fraction": a_HOCl,
+                "OCl_fraction": a_OCl, "effective_disinfection": a_HOCl}
+
+    def pH_dependent_chlorine_decay_factor(self, pH: float) -> float:
+        """chemistry.py:483-523."""
+        H = self.H_from_pH(pH)
+        return H / (H + self.Ka_HOCl) * 1.0 + self.Ka_HOCl / (H + self.Ka_HOCl) * 0.02
 
     def calculate_pH(self, initial_guess: float = 7.0, tolerance: float = PH_TOLERANCE,
                      max_iter: int = MAX_ITERATIONS) -> float:

@@ -14,7 +14,6 @@ from __future__ import annotations
 import ctypes as C
 import logging
 from dataclasses import dataclass, field, fields
-from types import SimpleNamespace
 from typing import Dict, Iterable, List, Optional, Sequence, Union
 
 import numpy as np
@@ -237,6 +236,7 @@ class ReactorEnsemble:
                        np.broadcast_to(np.asarray(cols["temperature"], dtype=np.float64)[:, None], shape),
                        np.zeros(self.n_reactors))
         self._boundary: Optional[np.ndarray] = None
+        self._device_boundary_moved = False     # the command path (plant I/O) rewrites the device's boundary block
 
     # -- lifetime
     def close(self) -> None:
@@ -260,8 +260,11 @@ class ReactorEnsemble:
 
     def set_boundary(self, boundaries) -> None:
         blk = boundary_block(boundaries, self.n_reactors)
+        if self._boundary is not None and not self._device_boundary_moved and np.array_equal(blk, self._boundary):
+            return                      # what the device already holds
         _native.check(_native.lib().wt_ensemble_set_boundary(self._h, _native.dptr(blk)))
-        self._boundary = blk
+        self._boundary = blk.copy()
+        self._device_boundary_moved = False
 
     def step(self, dt: float, boundaries=None, n_steps: int = 1, fused: bool = True,
              download: bool = True) -> Optional[EnsembleState]:
@@ -318,12 +321,12 @@ class ReactorEnsemble:
         pH, Cl, T = np.empty((N, n)), np.empty((N, n)), np.empty((N, n))
         H, rho, kd = np.empty((N, n)), np.empty((N, n)), np.empty((N, n))
         t, flow = np.empty(N), np.empty(N)
-        L = _native.lib()
-        _native.check(L.wt_ensemble_get_state(self._h, _native.dptr(pH), _native.dptr(Cl), _native.dptr(T),
-                                              _native.dptr(t), _native.dptr(flow)))
-        _native.check(L.wt_ensemble_get_derived(self._h, _native.dptr(H), _native.dptr(rho), _native.dptr(kd)))
+        st = np.zeros(N, dtype=np.uint32)
+        _native.check(_native.lib().wt_ensemble_get_snapshot(
+            self._h, _native.dptr(pH), _native.dptr(Cl), _native.dptr(T), _native.dptr(t), _native.dptr(flow),
+            _native.dptr(H), _native.dptr(rho), _native.dptr(kd), st.ctypes.data_as(C.POINTER(C.c_uint32))))
         return EnsembleState(time=t, pH=pH, chlorine=Cl, temperature=T, flow_rate=flow,
-                             H_concentration=H, density=rho, chlorine_decay_rate=kd, status=self.status())
+                             H_concentration=H, density=rho, chlorine_decay_rate=kd, status=st)
 
     def status(self) -> np.ndarray:
         st = np.zeros(self.n_reactors, dtype=np.uint32)
@@ -403,6 +406,7 @@ class ReactorEnsemble:
         input image is refreshed from the sensor readings (``update_modbus_inputs``) and the holding image
         is validated into the boundary conditions (``read_modbus_commands`` + ``apply_boundary_conditions``)."""
         _native.check(_native.lib().wt_ensemble_plc_enable(self._h))
+        self._device_boundary_moved = True
 
     @staticmethod
     def encode_float32(values) -> np.ndarray:
@@ -528,13 +532,9 @@ class IntegratedCSTR:
         self.config = config
         self._ens = ReactorEnsemble([config], device=device, validate=False)
         self._ens.set_step_limit(0)      # scipy's solve_ivp has no attempt limit (ReactorEnsemble keeps a guard)
+        self._last = None                # (pH, chlorine, temperature, time) as the device holds them, when known
         n = config.n_zones
-        c = self._ens.constants[:, 0]
-        self.transport = SimpleNamespace(
-            residence_time=params.residence_time_min(config.volume, config.flow_rate),
-            superficial_velocity=float(c[params.P_USUP]),
-            K_exchange_per_s=float(c[params.P_KEX]),
-            is_batch_mode=config.flow_rate == 0.0)
+        self._initialize_physics_modules()
         self.state = ReactorState(
             pH=np.full(n, config.initial_pH),
             chlorine=np.full(n, config.initial_chlorine),
@@ -544,6 +544,24 @@ class IntegratedCSTR:
         # flow_rate == 0 because residence_time is None)
         logger.info(f"Reactor initialized: {config.n_zones} zones, "
                     f"V={config.volume}L, τ={self.transport.residence_time:.1f}min")
+
+    def _initialize_physics_modules(self) -> None:
+        """The sub-objects the reference builds (reactor.py:229-270): host-side holders of the reactor's init-time
+        constants and scalar diagnostics; the step itself runs on the device from ``self._ens.constants``."""
+        from .chemistry import AqueousChemistry, BufferSystem
+        from .physics import (FlowParameters, GeometryParameters, SpatialModel, StratificationParameters,
+                              TemperatureDependentKinetics, TransportModel)
+        c = self.config
+        self.thermo = TemperatureDependentKinetics()
+        self.buffer = BufferSystem(alkalinity=c.alkalinity, total_carbonate=c.total_carbonate, temperature=c.temperature)
+        self.chemistry = AqueousChemistry(self.buffer, device=self._ens.device)
+        geometry = GeometryParameters(volume=c.volume, height=c.height, diameter=c.diameter, n_zones=c.n_zones)
+        flow = FlowParameters(flow_rate=c.flow_rate, turbulent_intensity=c.turbulent_intensity,
+                              recirculation_ratio=c.recirculation_ratio, impeller_speed=c.impeller_speed,
+                              impeller_diameter=c.impeller_diameter, power_number=c.power_number)
+        self.transport = TransportModel(geometry, flow, c.temperature)
+        self.spatial = SpatialModel(n_zones=c.n_zones, height=c.height, stratification_params=StratificationParameters(
+            enable_thermal_stratification=c.enable_thermal_stratification))
 
     def derivatives(self, t: float, y: np.ndarray, boundary: BoundaryConditions) -> np.ndarray:
         n = self.config.n_zones
@@ -560,9 +578,14 @@ class IntegratedCSTR:
         """Advance by ``dt`` seconds under ``boundary`` (reactor.py:450-509)."""
         ens = self._ens
         s = self.state
-        # honour host-side edits of self.state between steps (reactor.py:467-469)
-        ens.set_state(np.asarray(s.pH, dtype=np.float64)[None, :], np.asarray(s.chlorine, dtype=np.float64)[None, :],
-                      np.asarray(s.temperature, dtype=np.float64)[None, :], np.array([s.time], dtype=np.float64))
+        # honour host-side edits of self.state between steps (reactor.py:467-469): upload unless the state is
+        # exactly what the device left there
+        last = self._last
+        if not (last is not None and s.time == last[3] and np.array_equal(s.pH, last[0], equal_nan=True)
+                and np.array_equal(s.chlorine, last[1], equal_nan=True) and np.array_equal(s.temperature, last[2], equal_nan=True)):
+            ens.set_state(np.asarray(s.pH, dtype=np.float64)[None, :], np.asarray(s.chlorine, dtype=np.float64)[None, :],
+                          np.asarray(s.temperature, dtype=np.float64)[None, :], np.array([s.time], dtype=np.float64))
+        self._last = None
         es = ens.step(dt, boundary, n_steps=1)
         flags = int(es.status[0])
         if flags & ST_NONFINITE and float(es.time[0]) == float(s.time):
@@ -588,6 +611,8 @@ class IntegratedCSTR:
             logger.warning("Negative chlorine detected: clipped to 0")
         if flags & ST_CLAMP_T:
             logger.error("Temperature out of bounds: clipped to [0, 100]")
+        if flags == 0:
+            self._last = (s.pH.copy(), s.chlorine.copy(), s.temperature.copy(), s.time)
         return s
 
     def get_state_at_location(self, zone_idx: int, parameter: str) -> float:
@@ -627,6 +652,7 @@ class IntegratedCSTR:
         print("\n" + "=" * 70 + "\nCSTR PHYSICS DIAGNOSTICS\n" + "=" * 70)
         print(f"\nTime: {s.time:.1f} s")
         print(f"Residence time: {self.transport.residence_time:.1f} min")
+        print(f"Mixing time: {self.transport.mixing_time_seconds:.1f} s")
         print(f"\n{'Zone':<6} {'pH':<8} {'Cl(mg/L)':<10} {'T(°C)':<8} {'ρ(kg/m³)':<10}\n" + "-" * 50)
         for i in range(n):
             print(f"{i:<6} {s.pH[i]:<8.3f} {s.chlorine[i]:<10.3f} {s.temperature[i]:<8.2f} {s.density[i]:<10.2f}")

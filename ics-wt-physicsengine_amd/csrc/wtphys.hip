@@ -715,6 +715,21 @@ int wt_ensemble_get_state(wt_ensemble *h, double *pH, double *Cl, double *T, dou
     return WT_OK;
 }
 
+int wt_ensemble_get_snapshot(wt_ensemble *h, double *pH, double *Cl, double *T, double *time, double *flow,
+                             double *H, double *rho, double *kdecay, uint32_t *flags)
+{
+    if (!h) return fail(WT_E_ARG, "NULL handle");
+    HIP_TRY(hipSetDevice(h->device));
+    const size_t b = sizeof(double) * (size_t)h->N * h->n;
+    int rc;
+    if ((rc = d2h(h, pH, h->pH, b)) || (rc = d2h(h, Cl, h->Cl, b)) || (rc = d2h(h, T, h->T, b))) return rc;
+    if ((rc = d2h(h, time, h->time, sizeof(double) * h->N)) || (rc = d2h(h, flow, h->flow, sizeof(double) * h->N))) return rc;
+    if ((rc = d2h(h, H, h->dH, b)) || (rc = d2h(h, rho, h->dRho, b)) || (rc = d2h(h, kdecay, h->dK, b))) return rc;
+    if ((rc = d2h(h, flags, h->status, sizeof(uint32_t) * h->N))) return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return WT_OK;
+}
+
 int wt_ensemble_get_derived(wt_ensemble *h, double *H, double *rho, double *kdecay)
 {
     if (!h) return fail(WT_E_ARG, "NULL handle");

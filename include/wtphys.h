@@ -133,6 +133,9 @@ int wt_ensemble_synchronize(wt_ensemble *h);
  * pH/Cl/T [N][n]; time, flow [N]. Synchronises the stream. */
 int wt_ensemble_get_state(wt_ensemble *h, double *pH, double *Cl, double *T, double *time,
                           double *flow);
+/* everything a ReactorState holds plus the status words, one synchronisation (any pointer may be NULL) */
+int wt_ensemble_get_snapshot(wt_ensemble *h, double *pH, double *Cl, double *T, double *time, double *flow,
+                             double *H, double *rho, double *kdecay, uint32_t *flags);
 /* H_concentration, density, chlorine_decay_rate (reactor.py:511-524), [N][n] each. */
 int wt_ensemble_get_derived(wt_ensemble *h, double *H, double *rho, double *kdecay);
 int wt_ensemble_get_status(wt_ensemble *h, uint32_t *flags /* [N] */);

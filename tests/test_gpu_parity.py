@@ -543,3 +543,24 @@ def test_low_velocity_rhs_vs_reference(gpu, wt):
     assert np.allclose(dT, ref[:, 2 * n:], rtol=1e-13, atol=1e-16)
     assert np.allclose(dpH, ref[:, :n], rtol=1e-9, atol=1e-18) and np.allclose(dCl, ref[:, n:2 * n], rtol=1e-9, atol=1e-18)
     ens.close()
+
+
+def test_dropin_surface_and_reference_validators(gpu, wt, capsys):
+    """The drop-in carries the reference's sub-objects (reactor.py:229-270), prints its diagnostics report
+    (reactor.py:613-645) and passes the reference's own validation suite (core/__init__.py:266-294) on the GPU."""
+    r = wt.IntegratedCSTR(wt.ReactorConfiguration(n_zones=5))
+    assert isinstance(r.thermo, wt.TemperatureDependentKinetics) and isinstance(r.chemistry, wt.AqueousChemistry)
+    assert isinstance(r.transport, wt.TransportModel) and isinstance(r.spatial, wt.SpatialModel) and isinstance(r.buffer, wt.BufferSystem)
+    assert r.transport.K_exchange_per_s == r._ens.constants[wt.params.P_KEX, 0]
+    assert r.transport.superficial_velocity == r._ens.constants[wt.params.P_USUP, 0] and r.chemistry.Kw == r._ens.constants[wt.params.P_KW, 0]
+    assert abs(r.transport.mixing_time_seconds - 46.78) < 0.01 and r.transport.residence_time == 200.0
+    for _ in range(3):
+        r.step(1.0, wt.BoundaryConditions())
+    capsys.readouterr()
+    r.print_diagnostics()
+    out = capsys.readouterr().out
+    for line in ("CSTR PHYSICS DIAGNOSTICS", "Time: 3.0 s", "Residence time: 200.0 min", "Mixing time: 46.8 s", "Total Chlorine:",
+                 "pH segregation index:"):
+        assert line in out, line
+    wt.run_all_validations()
+    assert "ALL VALIDATIONS PASSED" in capsys.readouterr().out

@@ -111,3 +111,45 @@ def test_product_package_never_imports_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert "wt_oracle" not in text and "libwtoracle" not in text, f
+
+
+# the names wt_simulator.core exports (/root/reference/src/wt_simulator/core/__init__.py:238-263)
+REFERENCE_CORE_EXPORTS = ("IntegratedCSTR", "ReactorConfiguration", "ReactorState", "BoundaryConditions",
+                          "TemperatureDependentKinetics", "ArrheniusParameters", "AqueousChemistry", "BufferSystem",
+                          "TransportModel", "GeometryParameters", "FlowParameters", "SpatialModel", "StratificationParameters",
+                          "validate_thermodynamics", "validate_chemistry", "validate_transport", "validate_spatial",
+                          "validate_integrated_reactor")
+
+
+def test_import_surface_covers_the_reference_export_list(wt):
+    for name in REFERENCE_CORE_EXPORTS + ("run_all_validations",):
+        assert hasattr(wt, name) and name in wt.core.__all__, name
+
+
+def test_physics_subobjects_reproduce_reference_constants(wt):
+    """TransportModel / AqueousChemistry / TemperatureDependentKinetics / SpatialModel as host-side holders of the
+    init-time constants: bit-identical to what the reference's objects held (tests/golden/g1_constants.json)."""
+    g = golden_json("g1_constants.json")
+    for e in g["configs"]:
+        c = e["config"]
+        tm = wt.TransportModel(wt.GeometryParameters(c["volume"], c["height"], c["diameter"], c["n_zones"]),
+                               wt.FlowParameters(c["flow_rate"], c["turbulent_intensity"], c["recirculation_ratio"],
+                                                 c["impeller_speed"], c["impeller_diameter"], c["power_number"]), c["temperature"])
+        assert tm.K_exchange_per_s == e["K_exchange_per_s"] == tm.K_matrix[0, 1]
+        assert tm.superficial_velocity == e["superficial_velocity"] and tm.D_effective == e["D_effective"]
+        ch = wt.AqueousChemistry(wt.BufferSystem(c["alkalinity"], c["total_carbonate"], c["temperature"]))
+        assert (ch.Kw, ch.Ka1, ch.Ka2, ch.Ka_HOCl) == (e["Kw"], e["Ka1"], e["Ka2"], e["Ka_HOCl"])
+    th = wt.TemperatureDependentKinetics()
+    assert all(th.chlorine_decay_rate(float(T)) == v for T, v in g["k_decay"].items())
+    sp = wt.SpatialModel(5, 2.0)
+    assert all(sp.calculate_water_density(float(T)) == v for T, v in g["density"].items())
+    ch = wt.AqueousChemistry(wt.BufferSystem(100.0, 2.0, 20.0))
+    assert ch.buffering_capacity(7.2) == g["beta_7p2"] and ch.pH_dependent_chlorine_decay_factor(7.2) == g["decay_factor_7p2"]
+    with pytest.raises(ValueError, match="outside liquid water range"):
+        th.chlorine_decay_rate(100.5)
+
+
+def test_reference_validators_that_need_no_gpu(wt, capsys):
+    wt.validate_thermodynamics(); wt.validate_transport(); wt.validate_spatial()
+    out = capsys.readouterr().out
+    assert out.count("validations passed") == 3
