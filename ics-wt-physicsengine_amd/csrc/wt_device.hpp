@@ -219,8 +219,7 @@ struct RK {
     // chemistry.py:116-132 constants (frozen at configuration temperature)
     double Kw, Ka1, Ka1Ka2, KaH, cbeta;
     // transport / spatial: Richardson number (g drho dz) / (rho_avg u^2) against Ri_crit (spatial.py:262-277,293)
-    double Kex, dz, u2, ricrit, rihulp, supp;   // rihulp: half an ulp of Ri_crit
-    int strat_mode; // 0: stratification off, 1: Richardson test, 2: u<=1e-6 (Ri=+inf)
+    double Kex, dz, u2, ricrit, rihulp, supp, unsupp;   // rihulp: half an ulp of Ri_crit
     // boundary-derived (reactor.py:336,349-368,385-395,426-443)
     double Qv, H_in, Cl_in, T_in, acid_dH, cl_dose, UAr, T_amb;
     double flowsum;   // inlet + acid + chlorine flow: ReactorState.flow_rate (reactor.py:497-501)
@@ -255,10 +254,14 @@ __device__ __forceinline__ void load_reactor(const double *par, const double *bc
     const double u = P(9);
     k.dz = height / n;                          // spatial.py:119
     k.u2 = u * u;                               // velocity_scale ** 2
+    // the three cases of the stratification switch folded into the two outcomes of one branch-free test
+    // (rhs_rows): stratification off (reactor.py:310-315) -> factor 1 either way; velocity scale <= 1e-6 -> Ri = +inf,
+    // stable either way (spatial.py:270-275); else Ri against Ri_crit picks between the two
+    const int strat_mode = (P(10) != 0.0) ? ((u > 1e-6) ? 1 : 2) : 0;
     k.ricrit = P(11);
     k.rihulp = 0.5 * ulp_above_pos(k.ricrit);
-    k.supp = P(12);
-    k.strat_mode = (P(10) != 0.0) ? ((u > 1e-6) ? 1 : 2) : 0; // reactor.py:310, spatial.py:270-275
+    k.supp = (strat_mode != 0) ? P(12) : 1.0;        // interface factor where the Richardson test says "stable"
+    k.unsupp = (strat_mode == 2) ? P(12) : 1.0;      // ... and where it does not
     const double Q_in = B(0);
     k.Qv = (Q_in / 60.0) / V;                   // reactor.py:336
     k.H_in = exp10(-B(1));                      // reactor.py:363
@@ -297,7 +300,7 @@ struct RKStore { double *uni; double *lane; };          // uni[c * RK_MAXR], lan
 __device__ __forceinline__ void park_reactor(const RKStore &st, const RK &k)
 {
     const double u[RK_UNI] = {k.Kw, k.Ka1, k.Ka1Ka2, k.KaH, k.cbeta, k.dz, k.u2, k.supp, k.H_in, k.Cl_in, k.T_in, k.T_amb, k.UAr_on,
-                              (double)k.strat_mode, k.ricrit, k.flowsum, k.rihulp};
+                              k.unsupp, k.ricrit, k.flowsum, k.rihulp};
     const double l[RK_LANE] = {k.Kex_hi, k.Qv_in, k.Qv_out, k.acid0, k.dose0};
 #pragma unroll
     for (int c = 0; c < RK_UNI; ++c) st.uni[c * RK_MAXR] = u[c];     // every lane of the reactor stores the same value
@@ -311,7 +314,7 @@ __device__ __forceinline__ RK fetch_reactor(const RKStore &st)
     k.Kw = st.uni[0 * RK_MAXR]; k.Ka1 = st.uni[1 * RK_MAXR]; k.Ka1Ka2 = st.uni[2 * RK_MAXR]; k.KaH = st.uni[3 * RK_MAXR];
     k.cbeta = st.uni[4 * RK_MAXR]; k.dz = st.uni[5 * RK_MAXR]; k.u2 = st.uni[6 * RK_MAXR]; k.supp = st.uni[7 * RK_MAXR];
     k.H_in = st.uni[8 * RK_MAXR]; k.Cl_in = st.uni[9 * RK_MAXR]; k.T_in = st.uni[10 * RK_MAXR]; k.T_amb = st.uni[11 * RK_MAXR];
-    k.UAr_on = st.uni[12 * RK_MAXR]; k.strat_mode = (int)st.uni[13 * RK_MAXR]; k.ricrit = st.uni[14 * RK_MAXR]; k.rihulp = st.uni[16 * RK_MAXR];
+    k.UAr_on = st.uni[12 * RK_MAXR]; k.unsupp = st.uni[13 * RK_MAXR]; k.ricrit = st.uni[14 * RK_MAXR]; k.rihulp = st.uni[16 * RK_MAXR];
     k.Kex_hi = st.lane[0 * 64]; k.Qv_in = st.lane[1 * 64]; k.Qv_out = st.lane[2 * 64]; k.acid0 = st.lane[3 * 64]; k.dose0 = st.lane[4 * 64];
     return k;
 }
@@ -378,16 +381,12 @@ __device__ __forceinline__ void rhs_rows(const Lane &L, const RK &k, double H, d
     // fl(num / den) > c  <=>  num / den > c + ulp(c)/2  <=>  num - c den > (ulp(c)/2) den, and the left side is
     // exact in one fma whenever the two sides are close enough for rounding to matter: the same decision as the
     // reference's on the same bits, without a division.
+    // Stratification off / velocity scale <= 1e-6 (Ri = +inf) are folded into the two outcomes (load_reactor).
     const double rho_hi = from_hi<ROW, 1>(L, rho);
-    double s = 1.0;
-    if (k.strat_mode == 1) {
-        const double drho = rho_hi - rho;
-        const double ravg = 0.5 * (rho + rho_hi);
-        const double num = (9.81 * drho) * k.dz, den = ravg * k.u2;
-        if (__builtin_fma(-k.ricrit, den, num) > k.rihulp * den) s = k.supp;
-    } else if (k.strat_mode == 2) {
-        s = k.supp;
-    }
+    const double drho = rho_hi - rho;
+    const double ravg = 0.5 * (rho + rho_hi);
+    const double num = (9.81 * drho) * k.dz, den = ravg * k.u2;
+    const double s = (__builtin_fma(-k.ricrit, den, num) > k.rihulp * den) ? k.supp : k.unsupp;
     const double k_hi = k.Kex_hi * s;                     // K[i,i+1]  reactor.py:321-325 (0 above the top zone)
     const double k_lo = keep_m(L.m_lo[0], from_lo<ROW, 1>(L, k_hi)); // K[i,i-1] (bound_ctrl gives 0 below zone 0 of lane 0)
     const double kd = -(k_lo + k_hi) - k.Qv_out;          // reactor.py:329-337
