@@ -314,11 +314,11 @@ def run_rank(args) -> int:
             "config": {
                 "workload": (f"{total}-reactor x {n}-zone ensemble cut over {world} GPU(s) by reactor index "
                              f"({max(sizes)} per GPU)" if strong else f"{N}-reactor x {n}-zone ensemble per GPU")
-                            + f", dt=1 s, fp64, schedule {sched['mode']}: {sched['chunk']} outer step(s) per work item"
+                            + f", dt=1 s, fp64, {sched['mode']} schedule"
                             + (" + fused fp32 sensor suite" if args.sensors else "")
                             + (" + Modbus register image / command path per scan" if args.plant_io else ""),
                 "reactors_total": total, "reactors_per_gpu": max(sizes), "zones": n, "dt_s": 1.0,
-                "steps_per_item": sched["chunk"], "schedule": sched,
+                "scan_interval_steps": sched["chunk"], "schedule": sched,
                 "sharding": f"instance-parallel x{world} (contiguous reactor blocks, shard_bounds), final RCCL all_gather only",
             },
             "final_gather_ms": gather_ms,
@@ -332,7 +332,8 @@ def run_rank(args) -> int:
             # roofline of the dominant kernel (wt::step_kernel / wt::step_worker_kernel).  One launch
             # advances this rank's reactors by `steps` outer steps (persistent schedule) or one reactor
             # range by <= chunk steps (stream schedule); algorithmic bytes = per-unit figure x zone-steps.
-            per_unit = algorithmic_bytes_per_zone_step(n, sched["chunk"])
+            item_steps = ens.item_steps(args.steps)     # steps a reactor's state stays in registers between memory round trips
+            per_unit = algorithmic_bytes_per_zone_step(n, item_steps)
             avg_launch_s = launch_sum_ms * 1e-3 / max(n_launch, 1)
             in_flight = (launch_sum_ms / kernel_ms) if kernel_ms > 0 else 1.0   # launches overlapping on the GPU
             zs_per_launch = N * n * args.steps / max(n_launch, 1)
@@ -365,6 +366,7 @@ def run_rank(args) -> int:
                 "launches": n_launch,
                 "launches_in_flight": in_flight,
                 "algorithmic_bytes_per_zone_step": per_unit,
+                "steps_per_item": item_steps,
                 "algorithmic_bytes_per_launch": bytes_per_launch,
                 "formula": "achieved = (48 + (24 + 80/n)/steps_per_item) B x zone-steps per launch / avg_launch_us "
                            "x launches_in_flight (= all algorithmic bytes / HIP-event time of the timed region)",

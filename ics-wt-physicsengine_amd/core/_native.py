@@ -90,6 +90,8 @@ def lib():
     L.wt_ensemble_get_bad_temperature.restype = C.c_int
     L.wt_ensemble_item_trace.argtypes = [vp, C.POINTER(C.c_int64), C.c_int, C.POINTER(C.c_int)]
     L.wt_ensemble_item_trace.restype = C.c_int
+    L.wt_ensemble_item_steps.argtypes = [vp, C.c_int]
+    L.wt_ensemble_item_steps.restype = C.c_int
     L.wt_ensemble_queue_error.argtypes = [vp, C.POINTER(C.c_int)]
     L.wt_ensemble_queue_error.restype = C.c_int
     L.wt_ensemble_clear_status.argtypes = [vp]

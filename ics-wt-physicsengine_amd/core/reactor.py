@@ -295,6 +295,10 @@ class ReactorEnsemble:
         return {"mode": mode, "streams": s.value, "chunk": c.value, "workers": w.value,
                 "kernel": "wt::step_kernel" if mode == "streams" else "wt::step_worker_kernel"}
 
+    def item_steps(self, n_steps: int) -> int:
+        """Outer steps a reactor's state stays in registers before it returns to memory in a call of ``n_steps``."""
+        return int(_native.lib().wt_ensemble_item_steps(self._h, int(n_steps)))
+
     def set_step_limit(self, max_attempts: int) -> None:
         """Stop a reactor that needs more than ``max_attempts`` Radau step attempts in one outer step
         (status SOLVER_FAILED | STEP_LIMIT).  0 = unlimited, which is what the reference does."""

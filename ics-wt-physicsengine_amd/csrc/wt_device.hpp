@@ -295,7 +295,9 @@ __device__ __forceinline__ void mask_reactor_for_lane(const Lane &L, RK &k)
 // in LDS and fetched at the top of every RHS block: 14 per-reactor words (one copy per reactor, broadcast to
 // its lanes) and 5 per-lane ones.
 constexpr int RK_UNI = 17, RK_LANE = 5, RK_MAXR = 32;   // up to 32 reactors per wavefront (n = 2)
-struct RKStore { double *uni; double *lane; };          // uni[c * RK_MAXR], lane[c * 64]: already offset for this lane
+// reactors per wavefront a kernel instantiation can meet: LV levels serve n in (2^(LV-1), 2^LV]
+constexpr int rk_maxr(int LV) { return LV <= 1 ? 32 : 64 / ((1 << (LV - 1)) + 1); }
+struct RKStore { double *uni; double *lane; int stride; };   // uni[c * stride], lane[c * 64]: already offset for this lane
 
 __device__ __forceinline__ void park_reactor(const RKStore &st, const RK &k)
 {
@@ -303,7 +305,7 @@ __device__ __forceinline__ void park_reactor(const RKStore &st, const RK &k)
                               k.unsupp, k.ricrit, k.flowsum, k.rihulp};
     const double l[RK_LANE] = {k.Kex_hi, k.Qv_in, k.Qv_out, k.acid0, k.dose0};
 #pragma unroll
-    for (int c = 0; c < RK_UNI; ++c) st.uni[c * RK_MAXR] = u[c];     // every lane of the reactor stores the same value
+    for (int c = 0; c < RK_UNI; ++c) st.uni[c * st.stride] = u[c];   // every lane of the reactor stores the same value
 #pragma unroll
     for (int c = 0; c < RK_LANE; ++c) st.lane[c * 64] = l[c];
 }
@@ -311,10 +313,10 @@ __device__ __forceinline__ void park_reactor(const RKStore &st, const RK &k)
 __device__ __forceinline__ RK fetch_reactor(const RKStore &st)
 {
     RK k;
-    k.Kw = st.uni[0 * RK_MAXR]; k.Ka1 = st.uni[1 * RK_MAXR]; k.Ka1Ka2 = st.uni[2 * RK_MAXR]; k.KaH = st.uni[3 * RK_MAXR];
-    k.cbeta = st.uni[4 * RK_MAXR]; k.dz = st.uni[5 * RK_MAXR]; k.u2 = st.uni[6 * RK_MAXR]; k.supp = st.uni[7 * RK_MAXR];
-    k.H_in = st.uni[8 * RK_MAXR]; k.Cl_in = st.uni[9 * RK_MAXR]; k.T_in = st.uni[10 * RK_MAXR]; k.T_amb = st.uni[11 * RK_MAXR];
-    k.UAr_on = st.uni[12 * RK_MAXR]; k.unsupp = st.uni[13 * RK_MAXR]; k.ricrit = st.uni[14 * RK_MAXR]; k.rihulp = st.uni[16 * RK_MAXR];
+    k.Kw = st.uni[0 * st.stride]; k.Ka1 = st.uni[1 * st.stride]; k.Ka1Ka2 = st.uni[2 * st.stride]; k.KaH = st.uni[3 * st.stride];
+    k.cbeta = st.uni[4 * st.stride]; k.dz = st.uni[5 * st.stride]; k.u2 = st.uni[6 * st.stride]; k.supp = st.uni[7 * st.stride];
+    k.H_in = st.uni[8 * st.stride]; k.Cl_in = st.uni[9 * st.stride]; k.T_in = st.uni[10 * st.stride]; k.T_amb = st.uni[11 * st.stride];
+    k.UAr_on = st.uni[12 * st.stride]; k.unsupp = st.uni[13 * st.stride]; k.ricrit = st.uni[14 * st.stride]; k.rihulp = st.uni[16 * st.stride];
     k.Kex_hi = st.lane[0 * 64]; k.Qv_in = st.lane[1 * 64]; k.Qv_out = st.lane[2 * 64]; k.acid0 = st.lane[3 * 64]; k.dose0 = st.lane[4 * 64];
     return k;
 }
@@ -433,10 +435,21 @@ struct Jac {
 // A factor is written once per (h, J) and read once per solve, so LDS traffic is
 // off the fp64 VALU pipe that bounds this kernel, and the register file keeps
 // room for two wavefronts per SIMD.
-// For n > 8 (LV >= 4) the real-shift factors stay in registers instead (a lone wavefront has
-// them to spare) so that the LDS footprint still admits 4-5 wavefronts per CU.
+// For n > 8 (LV >= 4) the store outgrows what a wavefront may have of the CU's 160 KiB at four wavefronts per CU
+// (three at n > 32): the first NREG slots (real-shift factors) stay in registers instead.  All of them in LDS
+// means three wavefronts per CU at n = 20 and 0.6x the throughput (measured); all real-shift factors in registers
+// costs scratch spills -- so exactly as many as do not fit (n <= 32).
+constexpr int fstore_total_slots(int LV) { return 3 * (2 * LV + 1) + 3 * (4 * LV + 2); }
+constexpr int fstore_lds_slots(int LV)
+{
+    if (LV >= 6) return fstore_total_slots(LV) - 3 * (2 * LV + 1);                    // n > 32: three wavefronts per CU either way; registers measured faster
+    const int budget = 40960;                                                         // bytes per wavefront at four per CU
+    const int fixed = (RK_UNI * rk_maxr(LV) + RK_LANE * 64 + RK_MAXR / 2) * 8;        // LdsMap: reactor constants, history base
+    const int fit = (budget - fixed) / 512;
+    return fit < fstore_total_slots(LV) ? fit : fstore_total_slots(LV);
+}
 template <int LV> struct FStore {
-    static constexpr int NREG = (LV >= 4) ? 3 * (2 * LV + 1) : 0;   // slots [0, NREG) in registers
+    static constexpr int NREG = fstore_total_slots(LV) - fstore_lds_slots(LV);   // slots [0, NREG) in registers
     double reg[NREG > 0 ? NREG : 1];
     double *base;   // this lane's LDS column: base[(slot - NREG) * 64]
     // `slot` is a compile-time constant at every call site after inlining / unrolling
@@ -617,14 +630,17 @@ template <bool ROW, int LV>
 __device__ __forceinline__ void solve_rc(const Lane &L, const Jac &J, const FStore<LV> &F,
                                          double br[3], double cr[3], double ci[3])
 {
+    // Few levels: all three systems' factors are fetched ahead of their use (one exposed LDS round trip instead
+    // of three).  Many levels (n > 8): 6 LV + 3 doubles per system -- fetched system by system, or the three sets
+    // together overflow the register file into scratch.
     SysFactors<LV> sT, sP, sC;
     load_sys<LV>(F, 0, sT);
-    load_sys<LV>(F, 1, sP);
+    if constexpr (LV < 4) load_sys<LV>(F, 1, sP);
     // temperature block
     double xT = br[STT]; cplx zT = {cr[STT], ci[STT]};
     pcr_rc_level<ROW, LV, 0>(L, sT, xT, zT);
     xT *= sT.rinv; zT = cmul(zT, sT.cinv);
-    load_sys<LV>(F, 2, sC);
+    if constexpr (LV < 4) load_sys<LV>(F, 2, sC); else load_sys<LV>(F, 1, sP);
     const double xT_lo = keep_m(L.m_lo[0], from_lo<ROW, 1>(L, xT)), xT_hi = keep_m(L.m_hi[0], from_hi<ROW, 1>(L, xT));
     const cplx zT_lo = {keep_m(L.m_lo[0], from_lo<ROW, 1>(L, zT.r)), keep_m(L.m_lo[0], from_lo<ROW, 1>(L, zT.i))};
     const cplx zT_hi = {keep_m(L.m_hi[0], from_hi<ROW, 1>(L, zT.r)), keep_m(L.m_hi[0], from_hi<ROW, 1>(L, zT.i))};
@@ -634,6 +650,7 @@ __device__ __forceinline__ void solve_rc(const Lane &L, const Jac &J, const FSto
                ci[SPH] + (J.pt[0] * zT_lo.i + J.pt[1] * zT.i + J.pt[2] * zT_hi.i)};
     pcr_rc_level<ROW, LV, 0>(L, sP, xP, zP);
     xP *= sP.rinv; zP = cmul(zP, sP.cinv);
+    if constexpr (LV >= 4) load_sys<LV>(F, 2, sC);
     // chlorine block: rhs += J_cT x_T + J_cp x_p
     double xC = br[SCL] + (J.ct[0] * xT_lo + J.ct[1] * xT + J.ct[2] * xT_hi) + J.cp * xP;
     cplx zC = {cr[SCL] + (J.ct[0] * zT_lo.r + J.ct[1] * zT.r + J.ct[2] * zT_hi.r) + J.cp * zP.r,
@@ -893,7 +910,7 @@ __device__ __forceinline__ bool lane_setup(int64_t r0, int64_t r1, int n, int R,
 
 // LDS of one wavefront, ONE array: [reactor constants | history base | factor store, reused between outer steps as StepIO]
 template <int LV> struct LdsMap {
-    static constexpr int RK_DOUBLES = RK_UNI * RK_MAXR + RK_LANE * 64;
+    static constexpr int RK_DOUBLES = RK_UNI * rk_maxr(LV) + RK_LANE * 64;
     static constexpr int HIST_DOUBLES = RK_MAXR / 2;                      // RK_MAXR ints
     static constexpr int F_DOUBLES = FSlots<LV>::LDS_SLOTS * 64;
     static constexpr int IO_DOUBLES = (int)((sizeof(wts::StepIO) + 7) / 8);
@@ -990,7 +1007,7 @@ __device__ __forceinline__ void run_item(ArgPtr pa, const Lane &L, double *lds, 
     const double dt = a->dt;
     const int step_limit = a->step_limit, sens_on = a->sens.on, plc_on = a->sens.plc_on;
     const bool want_diag = a->wave_diag != nullptr;
-    const RKStore ks = {lds + seg, lds + RK_UNI * RK_MAXR + lane};
+    const RKStore ks = {lds + seg, lds + RK_UNI * rk_maxr(LV) + lane, rk_maxr(LV)};
     int *hist0 = reinterpret_cast<int *>(lds + M::RK_DOUBLES);
     double *lds_factors = lds + M::RK_DOUBLES + M::HIST_DOUBLES;
     wts::StepIO &io = *reinterpret_cast<wts::StepIO *>(lds_factors);
@@ -1400,7 +1417,7 @@ __device__ __forceinline__ void run_item(ArgPtr pa, const Lane &L, double *lds, 
                 for (int q = 0; q < 3; ++q) y0[q] = yc[q];
                 stepped = true; steps_done++;
                 t_out = t_out + dt;                    // reactor.py:496
-                flow_used = ks.uni[15 * RK_MAXR];      // reactor.py:497-501
+                flow_used = ks.uni[15 * ks.stride];    // reactor.py:497-501
                 // _update_derived_state reactor.py:511-524 (before the clamp)
                 dH = exp10(-y0[SPH]);
                 const PropT pt = prop_T(y0[STT]);

@@ -188,6 +188,18 @@ void launch_step(wt_ensemble *h, const wt::StepArgs &a, unsigned grid, hipStream
     if (timed) { (void)hipEventRecord(h->lt_pool[h->lt_used + 1], stream); h->lt_used += 2; }
 }
 
+// Outer steps per work item of the queue schedule.  A group changes hands at item boundaries, which costs a few
+// microseconds (state out and in, release / acquire), so not every step -- but often enough that the groups
+// sharing the workers take turns at least half a dozen times; at most 32 steps.
+int queue_item_steps(int n_steps)
+{
+    int item = n_steps / 6;
+    if (item > 32) item = 32;
+    if (item < 1) item = 1;
+    if (const char *e = getenv("WT_Q_ITEM")) item = atoi(e) > 0 ? atoi(e) : item;          // tuning knob (tools/)
+    return item;
+}
+
 // worker wavefronts of the queue schedule: as many as the device keeps resident (no more than there are groups)
 int queue_workers(const wt_ensemble *h)
 {
@@ -361,14 +373,9 @@ int wt_ensemble_step(wt_ensemble *h, double dt, int n_steps, int fused)
     if (h->wave_diag)
         HIP_TRY(hipMemsetAsync(h->wave_diag, 0, sizeof(int64_t) * wt::WT_DIAG_SLOTS * (size_t)h->n_groups, h->stream));
     if (h->sched_mode == WT_SCHED_QUEUE) {
-        // One launch.  Item length: a group changes hands at item boundaries, which costs a few microseconds
-        // (state out and in, release / acquire), so not every step -- but often enough that the groups sharing
-        // the workers take turns at least half a dozen times; at most 32 steps.
+        // One launch of q_workers worker wavefronts.
         const int W = h->q_workers > 0 ? h->q_workers : 1;
-        int64_t item = n_steps / 6;
-        if (item > 32) item = 32;
-        if (item < 1) item = 1;
-        if (const char *e = getenv("WT_Q_ITEM")) item = atoi(e) > 0 ? atoi(e) : item;          // tuning knob (tools/)
+        const int item = queue_item_steps(n_steps);
         wt::StepArgs a = make_args(h, dt, n_steps, 0, n_steps, chunk);
         a.q_ctrl = h->q_ctrl; a.q_slots = h->q_slots; a.q_next = h->q_next; a.q_cap = h->q_cap; a.item_steps = (int)item;
         {
@@ -637,6 +644,14 @@ int wt_ensemble_get_schedule(wt_ensemble *h, int *mode, int *n_streams, int *chu
     if (chunk_steps) *chunk_steps = h->chunk_steps;
     if (workers) *workers = h->sched_mode == WT_SCHED_QUEUE ? h->q_workers : 0;
     return WT_OK;
+}
+
+int wt_ensemble_item_steps(wt_ensemble *h, int n_steps)
+{
+    if (!h || n_steps <= 0) return 0;
+    if (h->sched_mode == WT_SCHED_QUEUE) return queue_item_steps(n_steps);
+    const int chunk = h->chunk_steps > 0 ? h->chunk_steps : n_steps;
+    return chunk < n_steps ? chunk : n_steps;
 }
 
 int wt_ensemble_queue_error(wt_ensemble *h, int *error)

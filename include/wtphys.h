@@ -114,6 +114,9 @@ int wt_ensemble_set_schedule(wt_ensemble *h, int n_streams, int chunk_steps);
  * worker wavefronts of the queue schedule (0 under WT_SCHED_STREAMS) */
 enum { WT_SCHED_STREAMS = 0, WT_SCHED_QUEUE = 1 };
 int wt_ensemble_get_schedule(wt_ensemble *h, int *mode, int *n_streams, int *chunk_steps, int *workers);
+/* outer steps a wavefront-group's state stays in registers before it goes back to memory, for a call of n_steps:
+ * the work-item length of the queue schedule (n_steps / 6, at most 32), the launch length of the stream schedule */
+int wt_ensemble_item_steps(wt_ensemble *h, int n_steps);
 /* != 0 after a launch whose work-queue hand-off gave up waiting (never observed; wt_ensemble_synchronize reports it) */
 int wt_ensemble_queue_error(wt_ensemble *h, int *error);
 /* Kept for ABI compatibility, no effect: the reactors sharing a wavefront always start an outer step
