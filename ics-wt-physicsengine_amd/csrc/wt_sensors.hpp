@@ -111,7 +111,10 @@ struct Rng {
         uint32_t x[4]; next(x);
         const float u1 = (float)((x[0] >> 8) + 1u) * (1.0f / 16777216.0f);
         const float u2 = (float)(x[1] >> 8) * (1.0f / 16777216.0f);
-        return scale * (sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2));
+        // hardware transcendentals: v_log_f32 (log2), v_sqrt_f32, v_cos_f32 (argument in revolutions, so u2 as it
+        // is); ~1e-6 absolute on z -- two orders below what the fp32 signal path is held to (tests: 2e-5)
+        const float l2 = __builtin_amdgcn_logf(u1);
+        return scale * (__builtin_amdgcn_sqrtf(-1.38629436111989061883f * l2) * __builtin_amdgcn_cosf(u2));
     }
 };
 
@@ -189,16 +192,36 @@ struct Line {
         const int oldest = max(0, pushes - RING);
         int c = max(cursor, oldest);
         const float target = t - 30.0f;
-        float tc = (c == pushes - 1) ? t : rt[(int64_t)(c % RING) * N];
+        // The winner moves on by about one entry per read, so the entries c .. c+3 are fetched in one go (eight
+        // independent loads, one memory round trip) instead of one dependent load per comparison; the walk below
+        // falls back to memory only beyond them.  The entry just pushed comes from registers.
+        constexpr int WIN = 4;
+        float wt[WIN], wv[WIN];
+#pragma unroll
+        for (int i = 0; i < WIN; ++i) {
+            const int j = c + i;
+            const bool mem = j < pushes - 1;
+            wt[i] = mem ? rt[(int64_t)(j % RING) * N] : t;
+            wv[i] = mem ? rv[(int64_t)(j % RING) * N] : tv;
+        }
+        const int c0 = c;
+        auto ts = [&](int j) -> float {
+            const int i = j - c0;
+            if (i < WIN) return i == 0 ? wt[0] : (i == 1 ? wt[1] : (i == 2 ? wt[2] : wt[3]));
+            return (j == pushes - 1) ? t : rt[(int64_t)(j % RING) * N];
+        };
+        float tc = wt[0];
         float dc = fabsf(tc - target);
         for (int j = c + 1; j < pushes; ++j) {
-            const float tj = (j == pushes - 1) ? t : rt[(int64_t)(j % RING) * N];
+            const float tj = ts(j);
             if (tj == tc) continue;                     // same timestamp: the earlier entry wins
             const float dj = fabsf(tj - target);
             if (!(dj < dc)) break;
             c = j; tc = tj; dc = dj;
         }
         cursor = c;
+        const int i = c - c0;
+        if (i < WIN) return i == 0 ? wv[0] : (i == 1 ? wv[1] : (i == 2 ? wv[2] : wv[3]));
         return (c == pushes - 1) ? tv : rv[(int64_t)(c % RING) * N];
     }
 };
