@@ -482,14 +482,16 @@ __device__ __forceinline__ void pcr_factor_level_all(const Lane &L, double ar[3]
     const bool vlo = L.z - s >= 0, vhi = L.z + s < L.n;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        // real shift
-        const double d_lo = from_lo<ROW, s>(L, dr[k]), d_hi = from_hi<ROW, s>(L, dr[k]);
+        // real shift.  Every lane inverts its own diagonal once and the neighbours fetch the reciprocal (the same
+        // bits as inverting the fetched diagonal on both sides, half the reciprocals)
+        const double id = rcp(dr[k]);
+        const double id_lo = from_lo<ROW, s>(L, id), id_hi = from_hi<ROW, s>(L, id);
         const double a_lo = from_lo<ROW, s>(L, ar[k]), c_lo = from_lo<ROW, s>(L, cr[k]);
         const double a_hi = from_hi<ROW, s>(L, ar[k]), c_hi = from_hi<ROW, s>(L, cr[k]);
         // a == 0 where there is no lower neighbour (c likewise), so alpha/gamma vanish there by
         // themselves once the foreign operands are finite
-        const double al = ar[k] * rcp(vlo ? d_lo : 1.0);
-        const double ga = cr[k] * rcp(vhi ? d_hi : 1.0);
+        const double al = ar[k] * (vlo ? id_lo : 1.0);
+        const double ga = cr[k] * (vhi ? id_hi : 1.0);
         dr[k] = dr[k] - al * keep_m(L.m_lo[l], c_lo) - ga * keep_m(L.m_hi[l], a_hi);
         ar[k] = -al * keep_m(L.m_lo[l], a_lo);
         cr[k] = -ga * keep_m(L.m_hi[l], c_hi);
@@ -497,14 +499,15 @@ __device__ __forceinline__ void pcr_factor_level_all(const Lane &L, double ar[3]
     }
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        // complex shift
-        const cplx d_lo = cfrom_lo<ROW, s>(L, dc[k]), d_hi = cfrom_hi<ROW, s>(L, dc[k]);
+        // complex shift, likewise
+        const cplx cid = cinv(dc[k]);
+        const cplx i_lo = cfrom_lo<ROW, s>(L, cid), i_hi = cfrom_hi<ROW, s>(L, cid);
         const cplx a_lo = cfrom_lo<ROW, s>(L, ac[k]), c_lo = cfrom_lo<ROW, s>(L, cc[k]);
         const cplx a_hi = cfrom_hi<ROW, s>(L, ac[k]), c_hi = cfrom_hi<ROW, s>(L, cc[k]);
-        const cplx dl = {vlo ? d_lo.r : 1.0, keep_m(L.m_lo[l], d_lo.i)};
-        const cplx dh = {vhi ? d_hi.r : 1.0, keep_m(L.m_hi[l], d_hi.i)};
-        const cplx al = cmul(ac[k], cinv(dl));
-        const cplx ga = cmul(cc[k], cinv(dh));
+        const cplx il = {vlo ? i_lo.r : 1.0, keep_m(L.m_lo[l], i_lo.i)};
+        const cplx ih = {vhi ? i_hi.r : 1.0, keep_m(L.m_hi[l], i_hi.i)};
+        const cplx al = cmul(ac[k], il);
+        const cplx ga = cmul(cc[k], ih);
         {   // d -= al * c_lo + ga * a_hi, eight fused multiply-adds
             const cplx cl = {keep_m(L.m_lo[l], c_lo.r), keep_m(L.m_lo[l], c_lo.i)};
             const cplx ah = {keep_m(L.m_hi[l], a_hi.r), keep_m(L.m_hi[l], a_hi.i)};
