@@ -246,6 +246,17 @@ int wt_ensemble_create(int64_t n_reactors, int n_zones, int device, const double
     HIP_TRY(hipSetDevice(device));
     wt_ensemble *h = new wt_ensemble();
     h->N = n_reactors; h->n = n_zones; h->R = 64 / n_zones; h->device = device;
+    {   // A small ensemble is spread over all SIMDs rather than packed into full wavefronts: a wavefront costs what
+        // its slowest reactor costs, so fewer reactors per wavefront is faster as long as every wavefront still
+        // finds a SIMD (about 4 per CU).  Results do not depend on it (reactors never interact).
+        int cus = 256; hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+        const int64_t slots = (int64_t)cus * 4;
+        int64_t r = (n_reactors + slots - 1) / slots;
+        if (const char *e = getenv("WT_FULL_WAVES")) if (atoi(e) != 0) r = h->R;      // tuning knob (tools/)
+        if (r < 1) r = 1;
+        if (r < h->R) h->R = (int)r;
+    }
     const size_t N = (size_t)n_reactors, nz = (size_t)n_zones;
     auto cleanup = [&]() { wt_ensemble_destroy(h); };
 #define ALLOC(ptr, bytes)                                                                   \
