@@ -293,7 +293,7 @@ class ReactorEnsemble:
         _native.check(_native.lib().wt_ensemble_get_schedule(self._h, C.byref(m), C.byref(s), C.byref(c), C.byref(w)))
         mode = {0: "streams", 1: "queue"}.get(m.value, str(m.value))
         return {"mode": mode, "streams": s.value, "chunk": c.value, "workers": w.value,
-                "kernel": "wt::step_kernel" if mode == "streams" else "wt::step_worker_kernel"}
+                "kernel": "wt::step_kernel"}
 
     def item_steps(self, n_steps: int) -> int:
         """Outer steps a reactor's state stays in registers before it returns to memory in a call of ``n_steps``."""
