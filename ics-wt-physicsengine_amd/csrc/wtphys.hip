@@ -384,16 +384,20 @@ int wt_ensemble_step(wt_ensemble *h, double dt, int n_steps, int fused)
     if (h->wave_diag)
         HIP_TRY(hipMemsetAsync(h->wave_diag, 0, sizeof(int64_t) * wt::WT_DIAG_SLOTS * (size_t)h->n_groups, h->stream));
     if (h->sched_mode == WT_SCHED_QUEUE) {
-        // One launch of q_workers worker wavefronts.
+        // One launch of q_workers worker wavefronts (more than one only if the call is so long that the queue's
+        // 32-bit tickets -- one per work item -- could run out: groups x items per launch stays below 2^30).
         const int W = h->q_workers > 0 ? h->q_workers : 1;
         const int item = queue_item_steps(n_steps);
-        wt::StepArgs a = make_args(h, dt, n_steps, 0, n_steps, chunk);
-        a.q_ctrl = h->q_ctrl; a.q_slots = h->q_slots; a.q_next = h->q_next; a.q_cap = h->q_cap; a.item_steps = (int)item;
-        {
+        int64_t per_launch = ((int64_t)1 << 30) / h->n_groups * item;
+        if (per_launch < item) per_launch = item;
+        for (int64_t done = 0; done < n_steps; done += per_launch) {
+            const int cnt = (int)((n_steps - done < per_launch) ? n_steps - done : per_launch);
+            wt::StepArgs a = make_args(h, dt, cnt, (int)done, n_steps, chunk);
+            a.q_ctrl = h->q_ctrl; a.q_slots = h->q_slots; a.q_next = h->q_next; a.q_cap = h->q_cap; a.item_steps = item;
             wt::QueueResetArgs qr{h->q_ctrl, h->q_slots, h->q_next, (int)h->n_groups, h->q_cap};
             hipLaunchKernelGGL(wt::queue_reset_kernel, dim3((unsigned)((h->q_cap + 255) / 256)), dim3(256), 0, h->stream, qr);
+            launch_step(h, a, (unsigned)W, h->stream);
         }
-        launch_step(h, a, (unsigned)W, h->stream);
         HIP_TRY(hipGetLastError());
         return WT_OK;
     }
