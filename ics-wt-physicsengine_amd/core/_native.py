@@ -36,7 +36,7 @@ class SolverStats(C.Structure):
 
 def build(force: bool = False, verbose: bool = False) -> str:
     """Compile csrc/wtphys.hip for gfx950 into csrc/libwtphys.so (hipcc)."""
-    srcs = [os.path.join(CSRC, f) for f in ("wtphys.hip", "wt_device.hpp", "wt_sensors.hpp", "wt_plc.hpp", "wt_diag.hpp")]
+    srcs = [os.path.join(CSRC, f) for f in ("wtphys.hip", "wt_device.hpp", "wt_triad.hpp", "wt_sensors.hpp", "wt_plc.hpp", "wt_diag.hpp")]
     srcs.append(os.path.join(os.path.dirname(_PKG), "include", "wtphys.h"))
     stale = (not os.path.exists(LIB_PATH)
              or os.path.getmtime(LIB_PATH) < max(os.path.getmtime(s) for s in srcs))

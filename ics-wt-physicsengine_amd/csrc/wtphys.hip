@@ -2,6 +2,9 @@
 // Owns device memory behind an opaque handle, uploads the SoA constant / boundary
 // blocks, launches the gfx950 kernels of wt_device.hpp on the handle's stream.
 #include "wt_device.hpp"
+#ifdef WT_TRIAD   // experiment builds only (tools/triad_check.py): one wavefront per species, DESIGN.md section 8
+#include "wt_triad.hpp"
+#endif
 #include "wt_diag.hpp"
 #include "../../include/wtphys.h"
 
@@ -55,6 +58,7 @@ struct wt_ensemble {
     int q_cap = 0, q_workers = 0;
     int64_t n_groups = 0;
     int sched_mode = WT_SCHED_QUEUE;
+    bool triad = false;           // experiment builds (-DWT_TRIAD): three wavefronts per group, one per species (wt_triad.hpp)
     int64_t *trace = nullptr; int trace_cap = 0;   // developer item trace (wt_ensemble_item_trace)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool have_bc = false, have_state = false;
@@ -142,26 +146,52 @@ int default_streams(int64_t n_reactors, int R)
 }
 
 // the kernel instantiation for this zone count
-template <class F> void with_step_kernel(int n, F &&f)
+template <class F> void with_step_kernel(const wt_ensemble *h, F &&f)
 {
+    const int n = h->n;
 #ifdef WT_ONLY_LV3   // scratch builds for kernel tuning: n in 5..8 only (n = 8 takes the row-shift variant)
-    (void)n; f(wt::step_kernel<3, true>);
+    (void)n;
+#ifdef WT_TRIAD
+    if (h->triad) { f(wt::tri::triad_kernel<3, true>, 192); return; }
+#endif
+    f(wt::step_kernel<3, true>, 64);
 #else
     const int lv = levels_for(n);
+#ifdef WT_TRIAD
+    if (h->triad) {
+        if (row_mode(n)) {
+            switch (lv) {
+            case 1: f(wt::tri::triad_kernel<1, true>, 192); break;
+            case 2: f(wt::tri::triad_kernel<2, true>, 192); break;
+            case 3: f(wt::tri::triad_kernel<3, true>, 192); break;
+            default: f(wt::tri::triad_kernel<4, true>, 192); break;
+            }
+        } else {
+            switch (lv) {
+            case 2: f(wt::tri::triad_kernel<2, false>, 192); break;
+            case 3: f(wt::tri::triad_kernel<3, false>, 192); break;
+            case 4: f(wt::tri::triad_kernel<4, false>, 192); break;
+            case 5: f(wt::tri::triad_kernel<5, false>, 192); break;
+            default: f(wt::tri::triad_kernel<6, false>, 192); break;
+            }
+        }
+        return;
+    }
+#endif
     if (row_mode(n)) { // n in {2,4,8,16}: every cross-lane move is a DPP row operation
         switch (lv) {
-        case 1: f(wt::step_kernel<1, true>); break;
-        case 2: f(wt::step_kernel<2, true>); break;
-        case 3: f(wt::step_kernel<3, true>); break;
-        default: f(wt::step_kernel<4, true>); break;
+        case 1: f(wt::step_kernel<1, true>, 64); break;
+        case 2: f(wt::step_kernel<2, true>, 64); break;
+        case 3: f(wt::step_kernel<3, true>, 64); break;
+        default: f(wt::step_kernel<4, true>, 64); break;
         }
     } else {
         switch (lv) {
-        case 2: f(wt::step_kernel<2, false>); break;
-        case 3: f(wt::step_kernel<3, false>); break;
-        case 4: f(wt::step_kernel<4, false>); break;
-        case 5: f(wt::step_kernel<5, false>); break;
-        default: f(wt::step_kernel<6, false>); break;
+        case 2: f(wt::step_kernel<2, false>, 64); break;
+        case 3: f(wt::step_kernel<3, false>, 64); break;
+        case 4: f(wt::step_kernel<4, false>, 64); break;
+        case 5: f(wt::step_kernel<5, false>, 64); break;
+        default: f(wt::step_kernel<6, false>, 64); break;
         }
     }
 #endif
@@ -169,7 +199,7 @@ template <class F> void with_step_kernel(int n, F &&f)
 
 void launch_step_raw(const wt_ensemble *h, const wt::StepArgs &a, unsigned grid, hipStream_t stream)
 {
-    with_step_kernel(h->n, [&](auto kernel) { hipLaunchKernelGGL(kernel, dim3(grid), dim3(64), 0, stream, a); });
+    with_step_kernel(h, [&](auto kernel, int block) { hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, stream, a); });
 }
 
 // one kernel launch, bracketed by HIP events on its own stream when launch timing is on
@@ -206,8 +236,8 @@ int queue_workers(const wt_ensemble *h)
     int per_cu = 0, cus = 0;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, h->device) == hipSuccess) cus = prop.multiProcessorCount;
-    with_step_kernel(h->n, [&](auto kernel) {
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 64, 0) != hipSuccess) per_cu = 0;
+    with_step_kernel(h, [&](auto kernel, int block) {
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block, 0) != hipSuccess) per_cu = 0;
     });
     if (cus <= 0) cus = 256;
     if (per_cu <= 0) per_cu = 4;
@@ -246,6 +276,9 @@ int wt_ensemble_create(int64_t n_reactors, int n_zones, int device, const double
     HIP_TRY(hipSetDevice(device));
     wt_ensemble *h = new wt_ensemble();
     h->N = n_reactors; h->n = n_zones; h->R = 64 / n_zones; h->device = device;
+#ifdef WT_TRIAD
+    if (const char *e = getenv("WT_KERNEL")) h->triad = std::string(e) == "triad";
+#endif
     {   // A small ensemble is spread over all SIMDs rather than packed into full wavefronts: a wavefront costs what
         // its slowest reactor costs, so fewer reactors per wavefront is faster as long as every wavefront still
         // finds a SIMD (about 4 per CU).  Results do not depend on it (reactors never interact).

@@ -12,10 +12,10 @@ import csv, glob, collections
 acc = collections.defaultdict(list)
 for f in glob.glob("gpurun_out/qpmc/p*/*counter_collection.csv"):
     for row in csv.DictReader(open(f)):
-        if "step_kernel" in row["Kernel_Name"]:
+        if "step_kernel" in row["Kernel_Name"] or "triad_kernel" in row["Kernel_Name"]:
             acc[row["Counter_Name"]].append(float(row["Counter_Value"]))
 last = {k: v[-1] for k, v in acc.items()}   # the timed launch
 waves = 1250.0; steps = 200.0
 for k in sorted(last):
-    print(f"{k:28s} {last[k]:.4e}  per wave-step {last[k]/waves/steps:10.1f}")
+    print(f"{k:28s} {last[k]:.4e}  per group-step {last[k]/waves/steps:10.1f}")
 EOP
