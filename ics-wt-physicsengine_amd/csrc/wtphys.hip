@@ -421,7 +421,9 @@ int wt_ensemble_step(wt_ensemble *h, double dt, int n_steps, int fused)
         // 32-bit tickets -- one per work item -- could run out: groups x items per launch stays below 2^30).
         const int W = h->q_workers > 0 ? h->q_workers : 1;
         const int item = queue_item_steps(n_steps);
-        int64_t per_launch = ((int64_t)1 << 30) / h->n_groups * item;
+        int64_t tickets = (int64_t)1 << 30;
+        if (const char *e = getenv("WT_Q_TICKETS")) if (atoll(e) > 0) tickets = atoll(e);     // test knob: force the split
+        int64_t per_launch = tickets / h->n_groups * item;
         if (per_launch < item) per_launch = item;
         for (int64_t done = 0; done < n_steps; done += per_launch) {
             const int cnt = (int)((n_steps - done < per_launch) ? n_steps - done : per_launch);

@@ -187,6 +187,30 @@ def test_results_do_not_depend_on_the_launch_schedule(gpu, wt, n):
         ens.close()
 
 
+def test_very_long_calls_are_split_without_a_trace(gpu, wt, monkeypatch):
+    """The queue's tickets are 32-bit: a call that would need more than 2^30 of them is cut into several launches
+    (wtphys.hip).  With the ticket budget turned down (WT_Q_TICKETS, test knob) a 23-step call becomes eight launches
+    of one 3-step item per group: state, counters, sensor readings, register images and the commanded boundary equal
+    the single launch's bit for bit."""
+    N, n, steps = 700, 8, 23
+    cols, bc = wt.make_ensemble(N, seed=77)
+    def run():
+        ens = wt.ReactorEnsemble(cols, n_zones=n); ens.set_boundary(bc)
+        ens.set_schedule(0, 5)
+        ens.enable_sensors(seed=5); ens.enable_plant_io()
+        ens.write_commands(0.1, 0.05, cols["flow_rate"] * 1.1)
+        assert ens.item_steps(steps) == 3
+        es = ens.step(1.0, n_steps=steps)
+        out = (es.pH, es.chlorine, es.temperature, es.time, es.status, ens.solver_stats(), *ens.sensor_readings(), *ens.input_image(), ens.boundary())
+        ens.close()
+        return out
+    ref = run()
+    monkeypatch.setenv("WT_Q_TICKETS", "1")                       # fewer tickets than groups: one item per group and launch
+    got = run()
+    for a, b in zip(ref, got):
+        assert np.array_equal(a, b, equal_nan=True)
+
+
 @pytest.mark.parametrize("n,N", [(2, 5), (3, 33), (5, 1), (7, 100), (16, 9), (31, 4), (64, 3)])
 def test_ragged_shapes_vs_oracle(gpu, wt, oracle, n, N):
     """Zone counts that do not divide 64, a single reactor, the 64-zone maximum."""
