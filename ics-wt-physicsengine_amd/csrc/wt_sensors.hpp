@@ -85,6 +85,10 @@ struct StepIO {
     float val[NSENS][RMAX];     // this step's readings, for the register image
     int fault[NSENS][RMAX];
     double cmd[3][RMAX];        // boundary rows in force after the command path: inlet, acid, chlorine flow
+    // sample-line hand-off from the line's first sensor (pH) to its second (RTD): appends / winner after the first,
+    // and the entry the first has just appended (push index, -1: none)
+    int lpush[2][RMAX], lcur[2][RMAX], lfresh[2][RMAX];
+    float lt[2][RMAX], lv[2][RMAX];
 };
 
 // ---------------------------------------------------------------- Philox4x32-10
@@ -140,12 +144,9 @@ __device__ __forceinline__ SensorSpec spec_of(int i, float fs)
 // vibration 0.1 <= 0.2), so they draw nothing; ambient temperature 30 degC enters the RTD stem error.
 constexpr float AMBIENT_T = 30.0f;
 
-// Sensors only interact through the two sample lines, so a reactor's suite splits into five independent
-// groups -- {pH_inlet, temp_inlet} (inlet line), {pH_outlet, temp_outlet} (outlet line), Cl_inlet,
-// Cl_outlet, flow -- and one thread runs one group of one reactor over the steps of a launch with the
-// group's state in registers.  blockIdx.y = group, so a wavefront executes one code path.
-constexpr int NGROUP = 5;
-
+// Sensors only interact through the two sample lines ({pH_inlet, temp_inlet} share the inlet line, {pH_outlet,
+// temp_outlet} the outlet line): one lane runs one sensor of one reactor, and the two sensors of a line take their
+// turns at it one after the other (suite_step).
 struct SState {
     float current, supply, cal_offset, last_value;
     double cal_time, power_on, last_t, prev_t, slow0, slow1, slow2;
@@ -184,6 +185,10 @@ template <class A> __device__ __forceinline__ void store_state(const A &a, int i
 // (the fp32 differences are exact, so equal distances only occur for equal or mirror-image timestamps).
 struct Line {
     float *rt, *rv; int64_t N; int pushes, cursor;
+    // an entry another lane of this wavefront appended during this read (taken from the hand-off, not from memory)
+    int fresh_j; float fresh_t, fresh_v;
+    __device__ __forceinline__ float mem_t(int j) const { return (j == fresh_j) ? fresh_t : rt[(int64_t)(j % RING) * N]; }
+    __device__ __forceinline__ float mem_v(int j) const { return (j == fresh_j) ? fresh_v : rv[(int64_t)(j % RING) * N]; }
     __device__ __forceinline__ float transport(float t, float tv)
     {
         const int slot = pushes % RING;
@@ -201,14 +206,14 @@ struct Line {
         for (int i = 0; i < WIN; ++i) {
             const int j = c + i;
             const bool mem = j < pushes - 1;
-            wt[i] = mem ? rt[(int64_t)(j % RING) * N] : t;
-            wv[i] = mem ? rv[(int64_t)(j % RING) * N] : tv;
+            wt[i] = mem ? mem_t(j) : t;
+            wv[i] = mem ? mem_v(j) : tv;
         }
         const int c0 = c;
         auto ts = [&](int j) -> float {
             const int i = j - c0;
             if (i < WIN) return i == 0 ? wt[0] : (i == 1 ? wt[1] : (i == 2 ? wt[2] : wt[3]));
-            return (j == pushes - 1) ? t : rt[(int64_t)(j % RING) * N];
+            return (j == pushes - 1) ? t : mem_t(j);
         };
         float tc = wt[0];
         float dc = fabsf(tc - target);
@@ -222,32 +227,36 @@ struct Line {
         cursor = c;
         const int i = c - c0;
         if (i < WIN) return i == 0 ? wv[0] : (i == 1 ? wv[1] : (i == 2 ? wv[2] : wv[3]));
-        return (c == pushes - 1) ? tv : rv[(int64_t)(c % RING) * N];
+        return (c == pushes - 1) ? tv : mem_v(c);
     }
 };
 
-// One BaseSensor.read + type-specific read() of sensor `sensor` at time t.  `tap` points at this reactor's
-// column of StepIO::tap (stride RMAX); lanes of one call run different sensors, so every branch on the
-// sensor kind is a lane mask.
-__device__ __forceinline__ void read_sensor(int sensor, SState &s, Line &ln, const float *tap, double t, float fs,
-                                            float &value, int &rstatus, int &rfault)
+// One BaseSensor.read + type-specific read() of sensor `sensor` at time t, in two halves around the sample line
+// (the two sensors of a line run in different lanes and take their turns at the line in between).  `tap` points at
+// this reactor's column of StepIO::tap (stride RMAX); lanes of one call run different sensors, so every branch on
+// the sensor kind is a lane mask.
+struct ReadCtx { bool cal_expired; float temp, tv; double cal_hours; };
+
+// up to the sample line; false: the read ended here (power fault, warming up)
+__device__ __forceinline__ bool read_begin(const SensorSpec &sp, SState &s, const float *tap, double t, ReadCtx &c,
+                                           float &value, int &rstatus, int &rfault)
 {
     constexpr int N = RMAX;
-    const SensorSpec sp = spec_of(sensor, fs);
     value = __builtin_nanf("");
     // ---------------- BaseSensor.read
     if (!(20.0f < s.supply && s.supply < 28.0f)) {                               // :549-569 (and stays so)
         rstatus = ST_POWER_FAULT; rfault = (s.supply < 20.0f) ? FL_POWER_LOW : FL_POWER_HIGH;
         s.prev_t = s.last_t; s.last_t = t; s.last_value = value; s.hist_n = min(s.hist_n + 1, 2);
-        return;
+        return false;
     }
     s.supply = 24.0f + s.rng.normal(1.0f);                                       // :572
     if (!(t - s.power_on >= (double)sp.warmup)) {                                // :575-588
         rstatus = ST_WARMING_UP; rfault = FL_NONE;
         s.prev_t = s.last_t; s.last_t = t; s.last_value = value; s.hist_n = min(s.hist_n + 1, 2);
-        return;
+        return false;
     }
-    const bool cal_expired = ((t - s.cal_time) / 3600.0 > (double)sp.cal_valid_h);   // :590-593
+    const double cal_hours = (t - s.cal_time) / 3600.0;
+    const bool cal_expired = (cal_hours > (double)sp.cal_valid_h);                   // :590-593
     if (cal_expired) s.status = ST_CAL_EXPIRED;
     const float temp = tap[sp.tap_T * N];
     float tv;
@@ -256,8 +265,17 @@ __device__ __forceinline__ void read_sensor(int sensor, SState &s, Line &ln, con
         const float ratio = exp10f(7.5f - tap[sp.tap_pH * N]);
         tv = tap[sp.tap_self * N] * (0.5f + 0.5f * (ratio / (1.0f + ratio)));
     } else tv = tap[sp.tap_self * N];                                            // flow_sensor.py:98-102, temperature_sensor.py:105-108
-    if (sp.line >= 0) tv = ln.transport((float)t, tv);                           // :598-609
-    const float drift = sp.drift_rate * (float)((t - s.cal_time) / 3600.0) + s.cal_offset;   // :612-616
+    c.cal_expired = cal_expired; c.temp = temp; c.tv = tv; c.cal_hours = cal_hours;
+    return true;
+}
+
+// from the sample line's output (c.tv) on                                                           :598-699
+__device__ __forceinline__ void read_finish(const SensorSpec &sp, SState &s, const ReadCtx &c, double t, float fs,
+                                            float &value, int &rstatus, int &rfault)
+{
+    const bool cal_expired = c.cal_expired;
+    const float temp = c.temp, tv = c.tv;
+    const float drift = sp.drift_rate * (float)c.cal_hours + s.cal_offset;       // :612-616
     const float noise = s.rng.normal(sp.precision);                              // :619
     float cur = 0.5f * (tv + noise + drift) + 0.5f * s.current;                  // :622-626 (hysteresis :630 is a no-op)
     float rate = 0.0f;                                                           // :638-648
@@ -295,48 +313,69 @@ __device__ __forceinline__ void read_sensor(int sensor, SState &s, Line &ln, con
     rstatus = s.status; rfault = s.fault; value = cur;
     if (!isfinite(cur)) return;
     // ---------------- type-specific read()
-    float fin;
+    // Every kind draws one to three normal deviates; the lanes of a wavefront run all kinds at once, so the draws are
+    // taken together -- first the scales of this kind's draws in the order the reference takes them, then up to
+    // three Philox calls for the whole wavefront instead of one call per draw and kind.
+    float sc1, sc2 = 0.0f, sc3 = 0.0f; int ndraw = 1;
+    double days = 0.0;
+    const double dday = dtp / 86400.0;           // (one division for every kind; the quotient is the same wherever it is formed)
     if (sp.kind == K_PH) {                                                       // ph_sensor.py:182-214,236-336
         // slow0 = membrane_fouling, slow1 = days_since_cleaning, slow2 = reference_contamination
         if (have_dt) {
             const double bio = (s.slow0 > 0.05) ? 0.1 * exp(0.05 * ((double)temp - 25.0)) : 0.001;
-            s.slow0 = fmin(1.0, s.slow0 + (bio + 100.0 * 0.00001) * (dtp / 86400.0));
-            s.slow1 += dtp / 86400.0;
+            s.slow0 = fmin(1.0, s.slow0 + (bio + 100.0 * 0.00001) * dday);
+            s.slow1 += dday;
         }
-        const float elec = s.rng.normal(0.002f * (1.0f + 0.1f * fabsf(cur - 7.0f)));
-        const float junc = s.rng.normal(0.005f * (1.0f + (float)s.slow2));
-        const double days = (t - s.cal_time) / 86400.0;
-        const float slope_pct = fmaxf(90.0f, 100.0f - 0.001f * (float)days);     // ph_sensor.py:262-266
-        float slope_err = 0.0f;
-        if (!(4.0f < cur && cur < 7.0f)) slope_err = fminf(fabsf(cur - 4.0f), fabsf(cur - 7.0f)) * (100.0f - slope_pct) / 100.0f;
-        const float foul_off = (float)s.slow0 * 0.2f;
-        const float foul_noise = s.rng.normal((float)s.slow0 * 0.05f);
-        s.slow2 = fmin(0.5, s.slow2 + 0.0001 * (days / 30.0));
-        fin = cur + elec + junc + slope_err + foul_off + foul_noise + (float)s.slow2 * 0.1f;
+        days = (t - s.cal_time) / 86400.0;
+        sc1 = 0.002f * (1.0f + 0.1f * fabsf(cur - 7.0f));                        // electrode noise
+        sc2 = 0.005f * (1.0f + (float)s.slow2);                                  // junction potential
+        sc3 = (float)s.slow0 * 0.05f;                                            // fouling noise
+        ndraw = 3;
     } else if (sp.kind == K_CL_AMP) {                                            // chlorine_sensor.py:310-331,405-449
         // slow0 = membrane fouling, slow1 = membrane age [d]
-        if (have_dt) { s.slow0 = fmin(1.0, s.slow0 + 0.01 * (dtp / 86400.0)); s.slow1 += dtp / 86400.0; }
-        const float pol = s.rng.normal(0.005f * (1.0f + (float)s.slow1 / 365.0f));
-        const float dif = s.rng.normal(0.003f);
-        fin = cur * (1.0f - 0.8f * (float)s.slow0) + pol + dif;
+        if (have_dt) { s.slow0 = fmin(1.0, s.slow0 + 0.01 * dday); s.slow1 += dday; }
+        sc1 = 0.005f * (1.0f + (float)s.slow1 / 365.0f);                         // polarisation
+        sc2 = 0.003f;                                                            // diffusion
+        ndraw = 2;
     } else if (sp.kind == K_CL_DPD) {                                            // chlorine_sensor.py:274-308,451-484
         // slow0 = reagent potency, slow1 = light exposure [h], slow2 = reagent age [d]
         if (have_dt) {
             s.slow1 += dtp / 3600.0;
             const double photo = 1.0 + 0.1 * (s.slow1 / 100.0);
-            s.slow0 = fmax(0.0, s.slow0 - 1.0 * photo * 0.01 * (dtp / 86400.0));
-            s.slow2 += dtp / 86400.0;
+            s.slow0 = fmax(0.0, s.slow0 - 1.0 * photo * 0.01 * dday);
+            s.slow2 += dday;
         }
-        fin = cur * (float)s.slow0 * 0.95f + s.rng.normal(0.005f);
+        sc1 = 0.005f;
     } else if (sp.kind == K_FLOW_MAG) {                                          // flow_sensor.py:138-178,201-219
-        if (have_dt) s.slow0 += 0.001 * (dtp / 86400.0);                         // electrode fouling
-        fin = cur * fmaxf(0.9f, 1.0f - 0.005f * (float)s.slow0) + s.rng.normal(0.001f * fs);
-        if (fin < 0.01f * fs) fin = 0.0f;
+        if (have_dt) s.slow0 += 0.001 * dday;                                    // electrode fouling
+        sc1 = 0.001f * fs;
     } else {                                                                     // temperature_sensor.py:149-171,118-128
+        sc1 = 0.001f;
+    }
+    const float z1 = s.rng.normal(sc1);
+    float z2 = 0.0f, z3 = 0.0f;
+    if (ndraw >= 2) z2 = s.rng.normal(sc2);
+    if (ndraw >= 3) z3 = s.rng.normal(sc3);
+    float fin;
+    if (sp.kind == K_PH) {
+        const float slope_pct = fmaxf(90.0f, 100.0f - 0.001f * (float)days);     // ph_sensor.py:262-266
+        float slope_err = 0.0f;
+        if (!(4.0f < cur && cur < 7.0f)) slope_err = fminf(fabsf(cur - 4.0f), fabsf(cur - 7.0f)) * (100.0f - slope_pct) / 100.0f;
+        const float foul_off = (float)s.slow0 * 0.2f;
+        s.slow2 = fmin(0.5, s.slow2 + 0.0001 * (days / 30.0));
+        fin = cur + z1 + z2 + slope_err + foul_off + z3 + (float)s.slow2 * 0.1f;
+    } else if (sp.kind == K_CL_AMP) {
+        fin = cur * (1.0f - 0.8f * (float)s.slow0) + z1 + z2;
+    } else if (sp.kind == K_CL_DPD) {
+        fin = cur * (float)s.slow0 * 0.95f + z1;
+    } else if (sp.kind == K_FLOW_MAG) {
+        fin = cur * fmaxf(0.9f, 1.0f - 0.005f * (float)s.slow0) + z1;
+        if (fin < 0.01f * fs) fin = 0.0f;
+    } else {
         const float R_meas = 100.0f * (1.0f + 0.00385f * cur) + 2.0f * 0.5f;
         const float power_mW = (1.0e-3f * 1.0e-3f) * R_meas * 1000.0f;
         const float T_meas = (R_meas / 100.0f - 1.0f) / 0.00385f;
-        fin = T_meas + 0.001f * power_mW + s.rng.normal(0.001f);
+        fin = T_meas + 0.001f * power_mW + z1;
         fin += 0.01f * (cur - AMBIENT_T);
     }
     fin = fminf(fmaxf(fin, sp.lo), sp.hi);
@@ -354,38 +393,59 @@ template <class A> __device__ __forceinline__ void emit(const A &a, int i, int64
 }
 
 // read_all_sensors (__main__.py:121-163) for the R reactors of this wavefront after one outer step; called by all
-// 64 lanes.  r_first: ensemble index of the wavefront's first reactor; hist0[s]: reads reactor s had taken before
-// this work item; k: outer steps of the item completed before this one.  Leaves the readings in io.val / io.fault.
+// 64 lanes.  One lane per sensor: lane l of a pass reads sensor l / R of reactor l % R (56 lanes at n = 8).  The only
+// coupling between sensors is the sample line a pH electrode shares with the RTD next to it: the reference reads
+// the pH sensor first (dict order), so the lanes of the pH sensors take their turn at the line, hand the line's
+// state on through LDS, then the lanes of the RTDs take theirs.
+// r_first: ensemble index of the wavefront's first reactor; hist0[s]: reads reactor s had taken before this work
+// item; k: outer steps of the item completed before this one.  Leaves the readings in io.val / io.fault.
 template <class A> __device__ __forceinline__ void suite_step(const A &a, StepIO &io, int64_t r_first, int R, const int *hist0, int k)
 {
     const int lane = threadIdx.x & 63;
-    for (int base = 0; base < NGROUP * R; base += 64) {
+    for (int base = 0; base < NSENS * R; base += 64) {
         const int idx = base + lane;
-        const int g = idx / R, sl = idx - g * R;            // sensor group, reactor slot
-        if (g >= NGROUP || !io.stepped[sl]) continue;
+        const int i = idx / R, sl = idx - i * R;            // sensor, reactor slot
+        const bool active = (i < NSENS) && io.stepped[sl];
         const int64_t r = r_first + sl, N = a.N;
-        const float fs = a.full_scale[r];
-        const double t = io.t_after[sl] - a.t_enable[r];
-        const int line = (g < 2) ? g : -1;                  // groups 0 / 1 own the inlet / outlet sample line
-        Line ln = {nullptr, nullptr, N, 0, 0};
-        if (line >= 0) {
-            ln.rt = a.ring_t + ((int64_t)line * RING) * N + r; ln.rv = a.ring_v + ((int64_t)line * RING) * N + r;
-            ln.pushes = a.ring_push[(int64_t)line * N + r]; ln.cursor = a.ring_cursor[(int64_t)line * N + r];
+        const int line = (i == 0 || i == 5) ? 0 : ((i == 1 || i == 6) ? 1 : -1);
+        const bool first = active && i < 2, second = active && i >= 5;
+        float fs = 0; double t = 0; int pos = 0;
+        float value = 0; int rstatus = 0, rfault = 0;
+        SState st; ReadCtx c = {false, 0.0f, 0.0f, 0.0}; bool go = false;
+        SensorSpec sp = spec_of(0, 0.0f);
+        Line ln = {nullptr, nullptr, N, 0, 0, -1, 0.0f, 0.0f};
+        if (active) {
+            fs = a.full_scale[r];
+            t = io.t_after[sl] - a.t_enable[r];
+            pos = hist0[sl] + k;
+            sp = spec_of(i, fs);
+            st = load_state(a, i, r);
+            go = read_begin(sp, st, &io.tap[0][sl], t, c, value, rstatus, rfault);
+            if (line >= 0) { ln.rt = a.ring_t + ((int64_t)line * RING) * N + r; ln.rv = a.ring_v + ((int64_t)line * RING) * N + r; }
         }
-        const int pos = hist0[sl] + k;
-        // first sensor of the group: pH_inlet, pH_outlet, chlorine_inlet, chlorine_outlet, flow_main; then, on
-        // the same sample line, temp_inlet / temp_outlet (read_all_sensors' dict order)
-        for (int sub = 0; sub < 2; ++sub) {
-            if (sub == 1 && g >= 2) break;
-            const int i = (sub == 0) ? g : 5 + g;
-            SState st = load_state(a, i, r);
-            float value; int rstatus, rfault;
-            read_sensor(i, st, ln, &io.tap[0][sl], t, fs, value, rstatus, rfault);
+        if (first) {                                         // SampleLine.transport_sample of the pH sensors  :598-609
+            ln.pushes = a.ring_push[(int64_t)line * N + r]; ln.cursor = a.ring_cursor[(int64_t)line * N + r];
+            const float pushed = c.tv;
+            if (go) c.tv = ln.transport((float)t, c.tv);
+            io.lpush[line][sl] = ln.pushes; io.lcur[line][sl] = ln.cursor;
+            io.lfresh[line][sl] = go ? ln.pushes - 1 : -1; io.lt[line][sl] = (float)t; io.lv[line][sl] = pushed;
+        }
+        // (one wavefront: its LDS operations complete in order; the fence only stops the compiler from moving them)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (second) {                                        // ... then of the RTDs on the same lines
+            ln.pushes = io.lpush[line][sl]; ln.cursor = io.lcur[line][sl];
+            ln.fresh_j = io.lfresh[line][sl]; ln.fresh_t = io.lt[line][sl]; ln.fresh_v = io.lv[line][sl];
+            if (go) c.tv = ln.transport((float)t, c.tv);
+            a.ring_push[(int64_t)line * N + r] = ln.pushes; a.ring_cursor[(int64_t)line * N + r] = ln.cursor;
+        }
+        if (active) {
+            if (go) read_finish(sp, st, c, t, fs, value, rstatus, rfault);
             store_state(a, i, r, st);
             emit(a, i, r, pos, value, rstatus, rfault);
             io.val[i][sl] = value; io.fault[i][sl] = rfault;
         }
-        if (line >= 0) { a.ring_push[(int64_t)line * N + r] = ln.pushes; a.ring_cursor[(int64_t)line * N + r] = ln.cursor; }
     }
 }
 
