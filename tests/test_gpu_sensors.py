@@ -89,16 +89,19 @@ def test_suite_statistics_and_independence(gpu, wt):
     assert np.unique(np.round(resid, 6)).size > 0.95 * resid.size
 
 
-def test_suite_at_config5_share_vs_oracle(gpu, wt):
+@pytest.mark.parametrize("N,n", [(12500, 8), (4000, 4), (4100, 2), (3000, 5)])
+def test_suite_at_config5_share_vs_oracle(gpu, wt, N, n):
     """BASELINE config 5's per-GPU share (12 500 reactors x 8 zones, sensors on): the readings of a sample of
     reactors over 45 steps against the sensor oracle fed the device's own per-step state; every wavefront position
-    (first / last reactor of a wavefront, last wavefront of the ensemble) is in the sample."""
+    (first / last reactor of a wavefront, last wavefront of the ensemble) is in the sample.  Likewise with 16, 32 and
+    12 reactors per wavefront, where the suite takes two / four passes of nine reactors (seven lanes each)."""
     import sensor_oracle as SO
-    N, n, steps, seed = 12500, 8, 45, 0xC0FFEE
+    steps, seed = 45, 0xC0FFEE
     cols, bc = wt.make_ensemble(N)
     ens = wt.ReactorEnsemble(cols, n_zones=n); ens.set_boundary(bc)
     ens.enable_sensors(seed=seed, reactor_base=0, history=steps)
-    sample = [0, 7, 8, 63, 64, 4099, 9999, 12488, 12495, 12496, 12499]
+    R = 64 // n
+    sample = sorted({0, R - 1, R, 8, 9, 10, 17, 18, 26, 27, 63, 64, N // 3, N // 3 + 9, N - R - 1, N - 5, N - 4, N - 1} & set(range(N)))
     suites = {r: SO.SensorSuite(float(cols["flow_rate"][r]), float(cols["initial_chlorine"][r]), float(cols["temperature"][r]),
                                 0.0, seed, r) for r in sample}
     ov = np.empty((steps, 7, len(sample))); os_ = np.empty((steps, 7, len(sample)), dtype=np.uint8); of = np.empty_like(os_)
