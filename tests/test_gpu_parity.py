@@ -211,6 +211,32 @@ def test_very_long_calls_are_split_without_a_trace(gpu, wt, monkeypatch):
         assert np.array_equal(a, b, equal_nan=True)
 
 
+def test_plain_c_client_equals_the_python_host(gpu, wt, tmp_path):
+    """tests/c_abi/abi_client.c (C99, gcc) drives create / set_state / set_boundary / step / get_state through
+    include/wtphys.h in its own process: same bits as the ctypes host."""
+    import subprocess
+    from test_host_api import _build_c_client
+    exe = _build_c_client(tmp_path)
+    N, n, steps, dt = 500, 8, 7, 1.0
+    cols, bc = wt.make_ensemble(N, seed=31)
+    ens = wt.ReactorEnsemble(cols, n_zones=n); ens.set_boundary(bc)
+    s0 = ens.state
+    req, rep = tmp_path / "req.bin", tmp_path / "rep.bin"
+    with open(req, "wb") as f:
+        np.array([N, n, steps], dtype=np.int64).tofile(f); np.array([dt]).tofile(f)
+        for arr in (ens.constants, bc, s0.pH, s0.chlorine, s0.temperature):
+            np.ascontiguousarray(arr, dtype=np.float64).tofile(f)
+    r = subprocess.run([exe, str(req), str(rep)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    out = np.fromfile(rep, dtype=np.float64)
+    es = ens.step(dt, n_steps=steps)
+    k = N * n
+    assert np.array_equal(out[:k].reshape(N, n), es.pH) and np.array_equal(out[k:2 * k].reshape(N, n), es.chlorine)
+    assert np.array_equal(out[2 * k:3 * k].reshape(N, n), es.temperature)
+    assert np.array_equal(out[3 * k:3 * k + N], es.time) and np.array_equal(out[3 * k + N:], es.status.astype(np.float64))
+    ens.close()
+
+
 @pytest.mark.parametrize("n,N", [(2, 5), (3, 33), (5, 1), (7, 100), (16, 9), (31, 4), (64, 3)])
 def test_ragged_shapes_vs_oracle(gpu, wt, oracle, n, N):
     """Zone counts that do not divide 64, a single reactor, the 64-zone maximum."""

@@ -153,3 +153,24 @@ def test_reference_validators_that_need_no_gpu(wt, capsys):
     wt.validate_thermodynamics(); wt.validate_transport(); wt.validate_spatial()
     out = capsys.readouterr().out
     assert out.count("validations passed") == 3
+
+
+def _build_c_client(tmp_path):
+    import os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "ics-wt-physicsengine_amd", "csrc")
+    exe = str(tmp_path / "abi_client")
+    subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(root, "include"),
+                    os.path.join(root, "tests", "c_abi", "abi_client.c"), "-L", csrc, "-lwtphys", f"-Wl,-rpath,{csrc}", "-o", exe],
+                   check=True)
+    return exe
+
+
+def test_boundary_is_plain_c(tmp_path):
+    """include/wtphys.h is valid strict C99 and a C program that drives the whole step path through it links against
+    csrc/libwtphys.so (no C++ or torch types in the signatures) -- the shape a cgo / JNI / FFI binding has."""
+    import subprocess
+    exe = _build_c_client(tmp_path)
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 1 and "usage" in r.stderr
+

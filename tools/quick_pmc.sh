@@ -7,7 +7,7 @@ for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES SQ_WAVE_CYCLES SQ_
   i=$((i+1))
   rocprofv3 --pmc $set --output-format csv -d $O/p$i -o p -- python3 bench.py --no-cpu-baseline --steps 200 --warmup 50 "$@" > $O/p$i.log 2>&1 || tail -3 $O/p$i.log
 done
-python3 - <<'EOP'
+python3 - ${WT_GROUPS:-1250} <<'EOP'
 import csv, glob, collections
 acc = collections.defaultdict(list)
 for f in glob.glob("gpurun_out/qpmc/p*/*counter_collection.csv"):
@@ -15,7 +15,8 @@ for f in glob.glob("gpurun_out/qpmc/p*/*counter_collection.csv"):
         if "step_kernel" in row["Kernel_Name"] or "triad_kernel" in row["Kernel_Name"]:
             acc[row["Counter_Name"]].append(float(row["Counter_Value"]))
 last = {k: v[-1] for k, v in acc.items()}   # the timed launch
-waves = 1250.0; steps = 200.0
+import sys
+waves = float(sys.argv[1]) if len(sys.argv) > 1 else 1250.0; steps = 200.0
 for k in sorted(last):
     print(f"{k:28s} {last[k]:.4e}  per group-step {last[k]/waves/steps:10.1f}")
 EOP
