@@ -1399,6 +1399,7 @@ __device__ __forceinline__ void run_item(ArgPtr pa, const Lane &L, double *lds, 
                 WT_STAMP(5);   // num_jac
             }
             last_cnt = cnt_s;
+
             // ================= after the solve: reactor.py:486-507
             if (raised) {
                 // the reference raised (thermodynamics.py:146-157): self.state untouched; name the temperature its
@@ -1458,7 +1459,7 @@ __device__ __forceinline__ void run_item(ArgPtr pa, const Lane &L, double *lds, 
                 if (!L.has_hi) { io.tap[1][seg] = (float)y0[SPH]; io.tap[3][seg] = (float)y0[SCL]; io.tap[5][seg] = (float)y0[STT]; }
             }
             __syncthreads();
-            { wts::SuitePre pre; wts::suite_step(b->sens, io, r_first, R, hist0, k, pre, false); }          // read_all_sensors
+            wts::suite_step(b->sens, io, r_first, R, hist0, k);          // read_all_sensors
             if (plc_on) {
                 const int gs = b->first_step + step0 + k;
                 const bool scan = ((gs + 1) % b->sens.scan_every == 0) || (gs + 1 == b->call_steps);

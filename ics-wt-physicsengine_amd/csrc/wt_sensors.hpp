@@ -85,9 +85,9 @@ struct StepIO {
     float val[NSENS][RMAX];     // this step's readings, for the register image
     int fault[NSENS][RMAX];
     double cmd[3][RMAX];        // boundary rows in force after the command path: inlet, acid, chlorine flow
-    // sample-line hand-off between the pH lane and the RTD lane that owns the line: whether the pH sensor samples the
-    // line in this read, when, and what (pH -> RTD: the true value; RTD -> pH: the delayed one)
-    int lgo[2][RMAX];
+    // sample-line hand-off from the line's first sensor (pH) to its second (RTD): appends / winner after the first,
+    // and the entry the first has just appended (push index, -1: none)
+    int lpush[2][RMAX], lcur[2][RMAX], lfresh[2][RMAX];
     float lt[2][RMAX], lv[2][RMAX];
 };
 
@@ -185,52 +185,37 @@ template <class A> __device__ __forceinline__ void store_state(const A &a, int i
 // (the fp32 differences are exact, so equal distances only occur for equal or mirror-image timestamps).
 struct Line {
     float *rt, *rv; int64_t N; int pushes, cursor;
-    // The winner moves on by an entry or two per read, so the entries the walk can reach are fetched ahead of the read
-    // (one memory round trip, in flight while the first half of the read computes); the walk falls back to memory only
-    // beyond them.  Entries appended during this read -- by either sensor of the line -- come from registers.
-    static constexpr int WIN = 6;
-    int w0, wp;                  // push index of wt[0]; appends at the time of the fetch (entries >= wp were not in memory)
-    float wt[WIN], wv[WIN];
-    int j1; float t1, v1;        // the entry appended by the previous transport of this read (-1: none)
-    __device__ __forceinline__ void fetch()
-    {
-        w0 = max(cursor, max(0, pushes + 1 - RING)); wp = pushes; j1 = -1; t1 = v1 = 0.0f;
-#pragma unroll
-        for (int i = 0; i < WIN; ++i) {
-            const int j = w0 + i;
-            const bool ok = j < wp;
-            wt[i] = ok ? rt[(int64_t)(j % RING) * N] : 0.0f;
-            wv[i] = ok ? rv[(int64_t)(j % RING) * N] : 0.0f;
-        }
-    }
-    __device__ __forceinline__ float sel(const float w[WIN], int i) const
-    {
-        return i == 0 ? w[0] : (i == 1 ? w[1] : (i == 2 ? w[2] : (i == 3 ? w[3] : (i == 4 ? w[4] : w[5]))));
-    }
+    // an entry another lane of this wavefront appended during this read (taken from the hand-off, not from memory)
+    int fresh_j; float fresh_t, fresh_v;
+    __device__ __forceinline__ float mem_t(int j) const { return (j == fresh_j) ? fresh_t : rt[(int64_t)(j % RING) * N]; }
+    __device__ __forceinline__ float mem_v(int j) const { return (j == fresh_j) ? fresh_v : rv[(int64_t)(j % RING) * N]; }
     __device__ __forceinline__ float transport(float t, float tv)
     {
-        const int own = pushes;
-        const int slot = own % RING;
+        const int slot = pushes % RING;
         rt[(int64_t)slot * N] = t; rv[(int64_t)slot * N] = tv;
         ++pushes;
         const int oldest = max(0, pushes - RING);
         int c = max(cursor, oldest);
         const float target = t - 30.0f;
+        // The winner moves on by about one entry per read, so the entries c .. c+3 are fetched in one go (eight
+        // independent loads, one memory round trip) instead of one dependent load per comparison; the walk below
+        // falls back to memory only beyond them.  The entry just pushed comes from registers.
+        constexpr int WIN = 4;
+        float wt[WIN], wv[WIN];
+#pragma unroll
+        for (int i = 0; i < WIN; ++i) {
+            const int j = c + i;
+            const bool mem = j < pushes - 1;
+            wt[i] = mem ? mem_t(j) : t;
+            wv[i] = mem ? mem_v(j) : tv;
+        }
+        const int c0 = c;
         auto ts = [&](int j) -> float {
-            if (j == own) return t;
-            if (j == j1) return t1;
-            const int i = j - w0;
-            if (i >= 0 && i < WIN && j < wp) return sel(wt, i);
-            return rt[(int64_t)(j % RING) * N];
+            const int i = j - c0;
+            if (i < WIN) return i == 0 ? wt[0] : (i == 1 ? wt[1] : (i == 2 ? wt[2] : wt[3]));
+            return (j == pushes - 1) ? t : mem_t(j);
         };
-        auto vs = [&](int j) -> float {
-            if (j == own) return tv;
-            if (j == j1) return v1;
-            const int i = j - w0;
-            if (i >= 0 && i < WIN && j < wp) return sel(wv, i);
-            return rv[(int64_t)(j % RING) * N];
-        };
-        float tc = ts(c);
+        float tc = wt[0];
         float dc = fabsf(tc - target);
         for (int j = c + 1; j < pushes; ++j) {
             const float tj = ts(j);
@@ -240,8 +225,9 @@ struct Line {
             c = j; tc = tj; dc = dj;
         }
         cursor = c;
-        j1 = own; t1 = t; v1 = tv;
-        return vs(c);
+        const int i = c - c0;
+        if (i < WIN) return i == 0 ? wv[0] : (i == 1 ? wv[1] : (i == 2 ? wv[2] : wv[3]));
+        return (c == pushes - 1) ? tv : mem_v(c);
     }
 };
 
@@ -406,94 +392,57 @@ template <class A> __device__ __forceinline__ void emit(const A &a, int i, int64
     }
 }
 
-// What a lane's sensor read needs from HBM, fetched ahead of the read (suite_prefetch: issued before the post-step
-// arithmetic of the physics, so the round trip is over when the suite starts).
-struct SuitePre { SState st; float fs; double t_enable; int pushes, cursor; };
-
-// lane -> (sensor, reactor slot) of pass `base`: the seven sensors of a reactor sit in adjacent lanes, nine reactors to
-// a pass, so a pass never splits a reactor (the two sensors of a sample line talk to each other within the pass)
-constexpr int PASS_REACTORS = 64 / NSENS;
-__device__ __forceinline__ void suite_lane(int pass, int R, int &i, int &sl, bool &exists)
+// read_all_sensors (__main__.py:121-163) for the R reactors of this wavefront after one outer step; called by all
+// 64 lanes.  One lane per sensor: lane l of a pass reads sensor l / R of reactor l % R (56 lanes at n = 8).  The only
+// coupling between sensors is the sample line a pH electrode shares with the RTD next to it: the reference reads
+// the pH sensor first (dict order), so the lanes of the pH sensors take their turn at the line, hand the line's
+// state on through LDS, then the lanes of the RTDs take theirs.
+// r_first: ensemble index of the wavefront's first reactor; hist0[s]: reads reactor s had taken before this work
+// item; k: outer steps of the item completed before this one.  Leaves the readings in io.val / io.fault.
+template <class A> __device__ __forceinline__ void suite_step(const A &a, StepIO &io, int64_t r_first, int R, const int *hist0, int k)
 {
     const int lane = threadIdx.x & 63;
-    const int q = lane / NSENS;
-    i = lane - q * NSENS; sl = pass * PASS_REACTORS + q;
-    exists = (q < PASS_REACTORS) && (sl < R);
-}
-__device__ __forceinline__ int line_of(int i) { return (i == 0 || i == 5) ? 0 : ((i == 1 || i == 6) ? 1 : -1); }
-
-template <class A> __device__ __forceinline__ void suite_load(const A &a, int i, int64_t r, SuitePre &p)
-{
-    const int64_t N = a.N;
-    p.st = load_state(a, i, r);
-    p.fs = a.full_scale[r];
-    p.t_enable = a.t_enable[r];
-    p.pushes = 0; p.cursor = 0;
-    if (i >= 5) { const int line = line_of(i); p.pushes = a.ring_push[(int64_t)line * N + r]; p.cursor = a.ring_cursor[(int64_t)line * N + r]; }
-}
-
-// pass 0's loads, for the lanes whose reactor exists (whether it completed the step is not known yet -- harmless)
-template <class A> __device__ __forceinline__ void suite_prefetch(const A &a, int64_t r_first, int R, SuitePre &p)
-{
-    int i, sl; bool exists;
-    suite_lane(0, R, i, sl, exists);
-    const int64_t r = r_first + sl;
-    if (exists && r < a.N) suite_load(a, i, r, p);
-}
-
-// read_all_sensors (__main__.py:121-163) for the R reactors of this wavefront after one outer step; called by all
-// 64 lanes.  One lane per sensor (63 lanes for nine reactors per pass; 56 at n = 8).  The only coupling between
-// sensors is the sample line a pH electrode shares with the RTD next to it, and the reference reads the pH sensor
-// first (dict order): the RTD's lane owns the line -- its state, the entries fetched ahead -- and performs the
-// line's turn of both sensors in that order; the pH lane hands its sample over through LDS and gets the delayed one
-// back.  So the line's state is loaded and stored by one lane only.
-// r_first: ensemble index of the wavefront's first reactor; hist0[s]: reads reactor s had taken before this work
-// item; k: outer steps of the item completed before this one; pre: pass 0's loads where pre_ok.  Leaves the readings
-// in io.val / io.fault.
-template <class A> __device__ __forceinline__ void suite_step(const A &a, StepIO &io, int64_t r_first, int R, const int *hist0, int k,
-                                                              SuitePre &pre, bool pre_ok)
-{
-    for (int pass = 0; pass * PASS_REACTORS < R; ++pass) {
-        int i, sl; bool exists;
-        suite_lane(pass, R, i, sl, exists);
+    for (int base = 0; base < NSENS * R; base += 64) {
+        const int idx = base + lane;
+        const int i = idx / R, sl = idx - i * R;            // sensor, reactor slot
+        const bool active = (i < NSENS) && io.stepped[sl];
         const int64_t r = r_first + sl, N = a.N;
-        const bool active = exists && r < N && io.stepped[sl];
-        const int line = line_of(i);
-        const bool owner = active && i >= 5, guest = active && i < 2;
-        if (active && (pass > 0 || !pre_ok)) suite_load(a, i, r, pre);
-        double t = 0; int pos = 0;
+        const int line = (i == 0 || i == 5) ? 0 : ((i == 1 || i == 6) ? 1 : -1);
+        const bool first = active && i < 2, second = active && i >= 5;
+        float fs = 0; double t = 0; int pos = 0;
         float value = 0; int rstatus = 0, rfault = 0;
-        ReadCtx c = {false, 0.0f, 0.0f, 0.0}; bool go = false;
+        SState st; ReadCtx c = {false, 0.0f, 0.0f, 0.0}; bool go = false;
         SensorSpec sp = spec_of(0, 0.0f);
-        Line ln; ln.rt = ln.rv = nullptr; ln.N = N; ln.pushes = ln.cursor = 0; ln.w0 = ln.wp = 0; ln.j1 = -1; ln.t1 = ln.v1 = 0.0f;
-        if (owner) {
-            ln.rt = a.ring_t + ((int64_t)line * RING) * N + r; ln.rv = a.ring_v + ((int64_t)line * RING) * N + r;
-            ln.pushes = pre.pushes; ln.cursor = pre.cursor;
-            ln.fetch();
-        }
+        Line ln = {nullptr, nullptr, N, 0, 0, -1, 0.0f, 0.0f};
         if (active) {
-            t = io.t_after[sl] - pre.t_enable;
+            fs = a.full_scale[r];
+            t = io.t_after[sl] - a.t_enable[r];
             pos = hist0[sl] + k;
-            sp = spec_of(i, pre.fs);
-            go = read_begin(sp, pre.st, &io.tap[0][sl], t, c, value, rstatus, rfault);
+            sp = spec_of(i, fs);
+            st = load_state(a, i, r);
+            go = read_begin(sp, st, &io.tap[0][sl], t, c, value, rstatus, rfault);
+            if (line >= 0) { ln.rt = a.ring_t + ((int64_t)line * RING) * N + r; ln.rv = a.ring_v + ((int64_t)line * RING) * N + r; }
         }
-        if (guest) { io.lgo[line][sl] = go ? 1 : 0; io.lt[line][sl] = (float)t; io.lv[line][sl] = c.tv; }
-        // (one wavefront: its LDS operations complete in order; the fences only stop the compiler from moving them)
+        if (first) {                                         // SampleLine.transport_sample of the pH sensors  :598-609
+            ln.pushes = a.ring_push[(int64_t)line * N + r]; ln.cursor = a.ring_cursor[(int64_t)line * N + r];
+            const float pushed = c.tv;
+            if (go) c.tv = ln.transport((float)t, c.tv);
+            io.lpush[line][sl] = ln.pushes; io.lcur[line][sl] = ln.cursor;
+            io.lfresh[line][sl] = go ? ln.pushes - 1 : -1; io.lt[line][sl] = (float)t; io.lv[line][sl] = pushed;
+        }
+        // (one wavefront: its LDS operations complete in order; the fence only stops the compiler from moving them)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (owner) {                                         // SampleLine.transport_sample, pH sensor first  :598-609
-            if (io.lgo[line][sl]) io.lv[line][sl] = ln.transport(io.lt[line][sl], io.lv[line][sl]);
+        if (second) {                                        // ... then of the RTDs on the same lines
+            ln.pushes = io.lpush[line][sl]; ln.cursor = io.lcur[line][sl];
+            ln.fresh_j = io.lfresh[line][sl]; ln.fresh_t = io.lt[line][sl]; ln.fresh_v = io.lv[line][sl];
             if (go) c.tv = ln.transport((float)t, c.tv);
             a.ring_push[(int64_t)line * N + r] = ln.pushes; a.ring_cursor[(int64_t)line * N + r] = ln.cursor;
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (guest && go) c.tv = io.lv[line][sl];
         if (active) {
-            if (go) read_finish(sp, pre.st, c, t, pre.fs, value, rstatus, rfault);
-            store_state(a, i, r, pre.st);
+            if (go) read_finish(sp, st, c, t, fs, value, rstatus, rfault);
+            store_state(a, i, r, st);
             emit(a, i, r, pos, value, rstatus, rfault);
             io.val[i][sl] = value; io.fault[i][sl] = rfault;
         }

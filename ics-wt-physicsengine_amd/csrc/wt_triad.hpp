@@ -1013,7 +1013,7 @@ __device__ __forceinline__ void run_item3(ArgPtr pa, const Lane &L, double *lds,
                 if (!L.has_hi) io.tap[2 * sp + 1][seg] = (float)y0;
             }
             __syncthreads();
-            if (sp == SCL) { wts::SuitePre pre; wts::suite_step(b->sens, io, r_first, R, hist0, k, pre, false); }   // read_all_sensors
+            if (sp == SCL) wts::suite_step(b->sens, io, r_first, R, hist0, k);          // read_all_sensors
             if (plc_on) {
                 const int gs = b->first_step + step0 + k;
                 const bool scan = ((gs + 1) % b->sens.scan_every == 0) || (gs + 1 == b->call_steps);
