@@ -3,6 +3,8 @@ reference's golden vectors.  Tolerance: per-zone pH / Cl / T within 1e-6
 relative of the reference CPU step (BASELINE.json north_star); observed
 agreement is orders of magnitude tighter and is asserted at 1e-7 for the
 golden trajectories and 1e-8 against the oracle on the bench ensemble."""
+import sys
+
 import numpy as np
 import pytest
 
@@ -209,6 +211,16 @@ def test_very_long_calls_are_split_without_a_trace(gpu, wt, monkeypatch):
     got = run()
     for a, b in zip(ref, got):
         assert np.array_equal(a, b, equal_nan=True)
+
+
+def test_device_export_and_rccl_gather(gpu):
+    """The multi-GPU path's device side on one card: wt_ensemble_export_state_device writes the (3, N, n) fp64 block
+    straight into a torch tensor, and gather_state runs the RCCL all_gather (world of one rank) on it.  In a process
+    of its own, torch first: torch brings its own HIP runtime, which must be the first one up (as in bench.py)."""
+    import os, subprocess
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "gpu_export_gather.py")],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "export and gather ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
 def test_plain_c_client_equals_the_python_host(gpu, wt, tmp_path):
