@@ -77,6 +77,9 @@ def build_parser() -> argparse.ArgumentParser:
     ap.add_argument("--cpu-sample-reactors", type=int, default=8192)
     ap.add_argument("--cpu-sample-steps", type=int, default=600)
     ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl")
+    ap.add_argument("--placement", choices=("adaptive", "identity"), default="adaptive",
+                    help="adaptive (library default): reactors of similar solver cost share a wavefront, re-dealt from the "
+                         "solver counters of the previous calls; identity: reactor r in slot r")
     ap.add_argument("--dry-run", action="store_true",
                     help="CPU rehearsal of the launcher / sharding / timing / gather logic (gloo, no HIP call, no "
                          "stepping): what tests/test_bench_launcher.py runs")
@@ -235,6 +238,7 @@ def run_rank(args) -> int:
             # the masters' setpoints = the synthetic boundary (as float32 registers), so the physics workload stays the same
             ens.write_commands(bc[4], bc[6], bc[0])
         ens.set_schedule(args.streams, max(1, args.chunk))
+        ens.set_placement(args.placement == "adaptive")
     sched = ens.schedule() if ens is not None else {"mode": "dry-run", "streams": 0, "chunk": args.chunk, "workers": 0}
 
     def barrier():

@@ -78,6 +78,8 @@ def lib():
     L.wt_ensemble_get_schedule.restype = C.c_int
     L.wt_ensemble_set_sync.argtypes = [vp, C.c_int]
     L.wt_ensemble_set_step_limit.argtypes = [vp, C.c_int]
+    L.wt_ensemble_set_placement.argtypes = [vp, C.c_int]
+    L.wt_ensemble_get_placement.argtypes = [vp, ip, i32p]
     L.wt_ensemble_launch_timing.argtypes = [vp, C.c_int]
     L.wt_ensemble_launch_stats.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.wt_ensemble_synchronize.argtypes = [vp]
@@ -124,7 +126,7 @@ def lib():
                  "wt_ensemble_clear_status", "wt_ensemble_get_stats", "wt_ensemble_rhs",
                  "wt_ensemble_export_state_device", "wt_ensemble_set_stream", "wt_ensemble_timer_start",
                  "wt_ensemble_diagnostics", "wt_ensemble_plc_enable", "wt_ensemble_plc_write_holding", "wt_ensemble_plc_read_inputs", "wt_ensemble_plc_device", "wt_ensemble_get_boundary",
-                 "wt_ensemble_timer_stop", "wt_ensemble_zones", "wt_ph_solve", "wt_selftest_shuffles", "wt_ensemble_wave_diag", "wt_ensemble_set_schedule", "wt_ensemble_set_sync", "wt_ensemble_set_step_limit", "wt_ensemble_sensors_enable", "wt_ensemble_sensors_get",
+                 "wt_ensemble_timer_stop", "wt_ensemble_zones", "wt_ph_solve", "wt_selftest_shuffles", "wt_ensemble_wave_diag", "wt_ensemble_set_schedule", "wt_ensemble_set_sync", "wt_ensemble_set_step_limit", "wt_ensemble_set_placement", "wt_ensemble_get_placement", "wt_ensemble_sensors_enable", "wt_ensemble_sensors_get",
                  "wt_ensemble_sensors_history", "wt_ensemble_launch_timing", "wt_ensemble_launch_stats"):
         getattr(L, name).restype = C.c_int
     if L.wt_abi_version() != 1:

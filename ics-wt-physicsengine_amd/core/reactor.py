@@ -288,12 +288,14 @@ class ReactorEnsemble:
         _native.check(_native.lib().wt_ensemble_set_schedule(self._h, int(n_streams), int(chunk_steps)))
 
     def schedule(self) -> Dict[str, object]:
-        """The schedule in force: {"mode", "streams", "chunk", "workers", "kernel"}."""
+        """The schedule in force: {"mode", "streams", "chunk", "workers", "kernel", "placement"}."""
         m, s, c, w = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)
         _native.check(_native.lib().wt_ensemble_get_schedule(self._h, C.byref(m), C.byref(s), C.byref(c), C.byref(w)))
         mode = {0: "streams", 1: "queue"}.get(m.value, str(m.value))
+        pm = C.c_int(0)
+        _native.check(_native.lib().wt_ensemble_get_placement(self._h, C.byref(pm), None))
         return {"mode": mode, "streams": s.value, "chunk": c.value, "workers": w.value,
-                "kernel": "wt::step_kernel"}
+                "kernel": "wt::step_kernel", "placement": "adaptive" if pm.value else "identity"}
 
     def item_steps(self, n_steps: int) -> int:
         """Outer steps a reactor's state stays in registers before it returns to memory in a call of ``n_steps``."""
@@ -303,6 +305,19 @@ class ReactorEnsemble:
         """Stop a reactor that needs more than ``max_attempts`` Radau step attempts in one outer step
         (status SOLVER_FAILED | STEP_LIMIT).  0 = unlimited, which is what the reference does."""
         _native.check(_native.lib().wt_ensemble_set_step_limit(self._h, int(max_attempts)))
+
+    def set_placement(self, adaptive: bool) -> None:
+        """Which reactors share a wavefront.  ``True`` (default): once 32 outer steps of solver counters are in, the
+        next :meth:`step` call re-deals the wavefront slots in order of solver cost, so a wavefront no longer waits for
+        one expensive reactor among cheap ones.  ``False``: reactor r in slot r.  Results do not depend on it."""
+        _native.check(_native.lib().wt_ensemble_set_placement(self._h, 1 if adaptive else 0))
+
+    def placement(self):
+        """(adaptive?, slot -> reactor index table)."""
+        mode = C.c_int(0)
+        perm = np.empty(self.n_reactors, dtype=np.int32)
+        _native.check(_native.lib().wt_ensemble_get_placement(self._h, C.byref(mode), perm.ctypes.data_as(C.POINTER(C.c_int32))))
+        return bool(mode.value), perm
 
     def set_sync(self, sync_outer: bool) -> None:
         _native.check(_native.lib().wt_ensemble_set_sync(self._h, 1 if sync_outer else 0))

@@ -97,6 +97,11 @@ struct StepArgs {
     int64_t *wave_diag;  // [n_groups][WT_DIAG_SLOTS] or nullptr, accumulated over the work items of a launch:
                          //   trips, Newton trips, shader clocks, wall clock (100 MHz), factorize / num_jac / deferred-f block executions, items
     double *bad_T;       // [N] the temperature the reference's ValueError names (thermodynamics.py:151)
+    // Placement: slot q of the wavefront-groups (group q / R, segment q % R) holds reactor perm[q].  Reactors never
+    // interact, so which of them share a wavefront is free -- and a wavefront costs what its slowest reactor costs,
+    // so reactors of similar solver cost are put together (wt_place.hpp re-bins them from `cost` between calls).
+    const int32_t *perm;  // [N]
+    int32_t *cost;        // [N] RHS evaluations since the last re-binning (the solver's nfev, summed over outer steps)
     double dt;
     int n_steps;      // outer steps this launch advances every reactor by
     int first_step;   // index of this launch's first step within the wt_ensemble_step call (PLC scan phase)
@@ -109,7 +114,7 @@ struct StepArgs {
     int64_t *trace; int trace_cap;   // optional item trace (tools/): worker, group, step0 | cnt << 32, start, end (100 MHz ticks)
     wts::SuiteArgs sens; // fused sensor suite + plant I/O (sens.on == 0: none)
 };
-enum { Q_AVAIL = 0, Q_HEAD = 1, Q_TAIL = 2, Q_ERROR = 3, Q_TRACE = 4, Q_WORDS = 16 };
+enum { Q_AVAIL = 0, Q_HEAD = 1, Q_TAIL = 2, Q_ERROR = 3, Q_TRACE = 4, Q_DONE = 5, Q_WORDS = 16 };
 
 // ---------------------------------------------------------------- lane geometry and cross-lane moves
 struct Lane {
@@ -444,7 +449,7 @@ constexpr int fstore_lds_slots(int LV)
 {
     if (LV >= 6) return fstore_total_slots(LV) - 3 * (2 * LV + 1);                    // n > 32: three wavefronts per CU either way; registers measured faster
     const int budget = 40960;                                                         // bytes per wavefront at four per CU
-    const int fixed = (RK_UNI * rk_maxr(LV) + RK_LANE * 64 + RK_MAXR / 2) * 8;        // LdsMap: reactor constants, history base
+    const int fixed = (RK_UNI * rk_maxr(LV) + RK_LANE * 64 + RK_MAXR) * 8;            // LdsMap: reactor constants, history base, reactor indices
     const int fit = (budget - fixed) / 512;
     return fit < fstore_total_slots(LV) ? fit : fstore_total_slots(LV);
 }
@@ -914,7 +919,7 @@ __device__ __forceinline__ bool lane_setup(int64_t r0, int64_t r1, int n, int R,
 // LDS of one wavefront, ONE array: [reactor constants | history base | factor store, reused between outer steps as StepIO]
 template <int LV> struct LdsMap {
     static constexpr int RK_DOUBLES = RK_UNI * rk_maxr(LV) + RK_LANE * 64;
-    static constexpr int HIST_DOUBLES = RK_MAXR / 2;                      // RK_MAXR ints
+    static constexpr int HIST_DOUBLES = RK_MAXR;                          // 2 x RK_MAXR ints: history base, reactor index of each segment
     static constexpr int F_DOUBLES = FSlots<LV>::LDS_SLOTS * 64;
     static constexpr int IO_DOUBLES = (int)((sizeof(wts::StepIO) + 7) / 8);
     static constexpr int TAIL_DOUBLES = F_DOUBLES > IO_DOUBLES ? F_DOUBLES : IO_DOUBLES;
@@ -922,12 +927,14 @@ template <int LV> struct LdsMap {
 };
 
 // ---- device-side work queue: FIFO of wavefront-groups that are ready for their next item (wave-uniform calls) ----
-// Tickets 0 .. n_groups-1 are the groups themselves (every group starts ready); ticket n_groups + p is the p-th push.
+// Tickets 0 .. n_groups-1 are the groups themselves, last group first (every group starts ready; the slots are dealt in
+// order of solver cost, so the expensive groups are the ones that must not start late); ticket n_groups + p is the
+// p-th push.
 // Q_AVAIL counts published, unclaimed entries, so a claimed ticket is always (about to be) written: the only wait
 // is for a pusher that sits between its tail increment and its slot store.
 __device__ __forceinline__ int queue_resolve(const StepArgs &a, int ticket)
 {
-    if (ticket < a.n_groups) return ticket;
+    if (ticket < a.n_groups) return a.n_groups - 1 - ticket;
     const unsigned long long want = (unsigned long long)(unsigned)(ticket + 1);
     unsigned long long *slot = a.q_slots + (ticket - a.n_groups) % a.q_cap;
     for (int spin = 0; spin < (1 << 22); ++spin) {
@@ -948,24 +955,26 @@ __device__ __forceinline__ void queue_push(const StepArgs &a, int group)
 }
 
 // Next group for this worker, or -1 to retire.  own >= 0: the group just advanced still has steps to go; it goes to
-// the back of the queue if another group is waiting (fair rotation: with more groups than resident wavefronts every
-// group advances at the same rate and nobody idles), otherwise this worker simply carries on with it.  Only an
+// the back of the queue if another group is waiting (rotation: with more groups than resident wavefronts nobody
+// idles) -- unless `hold`: the group is behind the ensemble's average progress (an expensive group: the same worker
+// time buys it fewer steps) and keeps its worker until it has caught up, so that all groups finish together instead of
+// the expensive ones trailing at the end of the launch.  Otherwise this worker simply carries on with it.  Only an
 // exchange hands data to another CU, so only then the wavefront releases what it wrote (and the taker acquires).
 // (Tried and dropped: letting groups whose items run long keep their worker, and dealing last launch's slow groups
 // first -- a group's cost comes in bursts when a reactor crosses a stratification switch, not as a persistent rate,
 // so neither shortens the tail of a short launch; see DESIGN.md.)
-__device__ __forceinline__ int queue_next(const StepArgs &a, int own, bool &exchanged)
+__device__ __forceinline__ int queue_next(const StepArgs &a, int own, bool hold, bool &exchanged)
 {
     const bool lane0 = (threadIdx.x & 63) == 0;
     int ticket = -1;
-    if (lane0) {
+    if (lane0 && !(own >= 0 && hold)) {
         const int old = __hip_atomic_fetch_add(a.q_ctrl + Q_AVAIL, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (old > 0) ticket = __hip_atomic_fetch_add(a.q_ctrl + Q_HEAD, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         else __hip_atomic_fetch_add(a.q_ctrl + Q_AVAIL, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     ticket = __builtin_amdgcn_readfirstlane(ticket);
     exchanged = ticket >= 0;
-    if (ticket < 0) return own;                 // nothing waiting: carry on with the own group, or retire
+    if (ticket < 0) return own;                 // nothing waiting (or holding on): carry on with the own group, or retire
     if (own >= 0) {
         // publish the group's state before anybody can take its next item
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1002,16 +1011,17 @@ __device__ __forceinline__ void run_item(ArgPtr pa, const Lane &L, double *lds, 
     ArgPtr a = fresh(pa);                             // ---- section: load the group
     const int n_zones = a->n, R = a->R;
     const int lane = threadIdx.x & 63, seg = lane / n_zones;
-    const int64_t r_first = (int64_t)group * R;
-    const int64_t r_end = a->q_ctrl ? a->N : a->r1;
-    const int64_t r = r_first + seg;
-    const bool present = (seg < R) && (r < r_end);
+    const int64_t q_first = (int64_t)group * R;       // slots of this group; slot q holds reactor perm[q]
+    const int64_t q_end = a->q_ctrl ? a->N : a->r1;
+    const bool present = (seg < R) && (q_first + seg < q_end);
+    const int64_t r = present ? (int64_t)a->perm[q_first + seg] : 0;
     const int64_t idx = r * n_zones + L.z;
     const double dt = a->dt;
     const int step_limit = a->step_limit, sens_on = a->sens.on, plc_on = a->sens.plc_on;
     const bool want_diag = a->wave_diag != nullptr;
     const RKStore ks = {lds + seg, lds + RK_UNI * rk_maxr(LV) + lane, rk_maxr(LV)};
     int *hist0 = reinterpret_cast<int *>(lds + M::RK_DOUBLES);
+    int *rix = hist0 + RK_MAXR;                       // reactor index of each segment, for the sensor / PLC lanes
     double *lds_factors = lds + M::RK_DOUBLES + M::HIST_DOUBLES;
     wts::StepIO &io = *reinterpret_cast<wts::StepIO *>(lds_factors);
 
@@ -1023,7 +1033,7 @@ __device__ __forceinline__ void run_item(ArgPtr pa, const Lane &L, double *lds, 
     double flow_used = 0;                             // ReactorState.flow_rate: the flows of the last step taken
     uint32_t st = 0;
     bool frozen = !present, f_valid = false, wrote_k = false, raised = false;
-    int steps_done = 0;
+    int steps_done = 0, cost_acc = 0;
     SolverCounters last_cnt = {0, 0, 0, 0, 0};
     long long diag_trips = 0, diag_newton = 0, diag_fact = 0, diag_jac = 0, diag_f3 = 0;
 #ifdef WT_STAMPS  // diagnostic build only: shader-clock shares of the loop's sections (never in the product .so)
@@ -1042,6 +1052,7 @@ __device__ __forceinline__ void run_item(ArgPtr pa, const Lane &L, double *lds, 
         RK k0; load_reactor(a->par, a->bc, a->N, r, n_zones, k0); mask_reactor_for_lane(L, k0);
         park_reactor(ks, k0);
         if (sens_on && L.z == 0) hist0[seg] = a->sens.hist_value ? a->sens.hist_pos[r] : 0;
+        if (L.z == 0) rix[seg] = (int)r;
     }
 
     for (int k = 0; k < cnt; ++k) {
@@ -1399,6 +1410,7 @@ __device__ __forceinline__ void run_item(ArgPtr pa, const Lane &L, double *lds, 
                 WT_STAMP(5);   // num_jac
             }
             last_cnt = cnt_s;
+            cost_acc += cnt_s.nfev;
 
             // ================= after the solve: reactor.py:486-507
             if (raised) {
@@ -1459,13 +1471,13 @@ __device__ __forceinline__ void run_item(ArgPtr pa, const Lane &L, double *lds, 
                 if (!L.has_hi) { io.tap[1][seg] = (float)y0[SPH]; io.tap[3][seg] = (float)y0[SCL]; io.tap[5][seg] = (float)y0[STT]; }
             }
             __syncthreads();
-            wts::suite_step(b->sens, io, r_first, R, hist0, k);          // read_all_sensors
+            wts::suite_step(b->sens, io, rix, R, hist0, k);              // read_all_sensors
             if (plc_on) {
                 const int gs = b->first_step + step0 + k;
                 const bool scan = ((gs + 1) % b->sens.scan_every == 0) || (gs + 1 == b->call_steps);
                 __syncthreads();
                 if (lane < R && io.stepped[lane]) {                       // one lane per reactor
-                    const int64_t rr = r_first + lane;
+                    const int64_t rr = rix[lane];
                     const double lt = b->sens.pack.loop_time[rr];
                     if (scan) {
                         wtp::pack_inputs(b->sens.pack, rr, &io.val[0][lane], &io.fault[0][lane], wts::RMAX, lt);   // update_modbus_inputs
@@ -1509,6 +1521,7 @@ __device__ __forceinline__ void run_item(ArgPtr pa, const Lane &L, double *lds, 
             }
             c->status[r] = st;
             if (st & (ST_T_RANGE | ST_T_RANGE_POST)) c->bad_T[r] = badval;
+            if (c->cost && cost_acc > 0) c->cost[r] += cost_acc;
         }
     }
     if (want_diag && lane == 0) {
@@ -1548,7 +1561,7 @@ __global__ __launch_bounds__(64) void step_kernel(const StepArgs a)
     const ArgPtr pa = (ArgPtr)__builtin_amdgcn_kernarg_segment_ptr();
     const bool queue = a.q_ctrl != nullptr;
     bool exchanged = true;
-    int group = queue ? queue_next(a, -1, exchanged) : (int)(a.r0 / a.R) + (int)blockIdx.x;
+    int group = queue ? queue_next(a, -1, false, exchanged) : (int)(a.r0 / a.R) + (int)blockIdx.x;
     while (group >= 0) {          // (one call site: the item body exists once in the code object)
         int step0 = 0, cnt = a.n_steps;
         long long t0 = 0;
@@ -1564,8 +1577,13 @@ __global__ __launch_bounds__(64) void step_kernel(const StepArgs a)
         run_item<LV, ROW>(pa, L, lds, group, step0, cnt);
         if (!queue) break;
         const bool more = step0 + cnt < a.n_steps;
+        int hold = 0;
         if ((threadIdx.x & 63) == 0) {
             __hip_atomic_store(a.q_next + group, step0 + cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // items this group has behind it against the ensemble's average
+            const long long done = __hip_atomic_fetch_add(a.q_ctrl + Q_DONE, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+            const long long mine = (step0 + cnt + a.item_steps - 1) / a.item_steps;
+            hold = (mine * a.n_groups < done) ? 1 : 0;
             if (a.trace) {
                 const int slot = __hip_atomic_fetch_add(a.q_ctrl + Q_TRACE, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (slot < a.trace_cap) {
@@ -1574,7 +1592,8 @@ __global__ __launch_bounds__(64) void step_kernel(const StepArgs a)
                 }
             }
         }
-        group = queue_next(a, more ? group : -1, exchanged);
+        hold = __builtin_amdgcn_readfirstlane(hold);
+        group = queue_next(a, more ? group : -1, hold != 0, exchanged);
     }
 }
 

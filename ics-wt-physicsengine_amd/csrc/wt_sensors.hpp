@@ -397,16 +397,16 @@ template <class A> __device__ __forceinline__ void emit(const A &a, int i, int64
 // coupling between sensors is the sample line a pH electrode shares with the RTD next to it: the reference reads
 // the pH sensor first (dict order), so the lanes of the pH sensors take their turn at the line, hand the line's
 // state on through LDS, then the lanes of the RTDs take theirs.
-// r_first: ensemble index of the wavefront's first reactor; hist0[s]: reads reactor s had taken before this work
+// rix[s]: ensemble index of the reactor in segment s; hist0[s]: reads reactor s had taken before this work
 // item; k: outer steps of the item completed before this one.  Leaves the readings in io.val / io.fault.
-template <class A> __device__ __forceinline__ void suite_step(const A &a, StepIO &io, int64_t r_first, int R, const int *hist0, int k)
+template <class A> __device__ __forceinline__ void suite_step(const A &a, StepIO &io, const int *rix, int R, const int *hist0, int k)
 {
     const int lane = threadIdx.x & 63;
     for (int base = 0; base < NSENS * R; base += 64) {
         const int idx = base + lane;
         const int i = idx / R, sl = idx - i * R;            // sensor, reactor slot
         const bool active = (i < NSENS) && io.stepped[sl];
-        const int64_t r = r_first + sl, N = a.N;
+        const int64_t r = rix[sl & (RMAX - 1)], N = a.N;
         const int line = (i == 0 || i == 5) ? 0 : ((i == 1 || i == 6) ? 1 : -1);
         const bool first = active && i < 2, second = active && i >= 5;
         float fs = 0; double t = 0; int pos = 0;

@@ -46,7 +46,7 @@ constexpr int TRIP_CAP = 1 << 20;      // no outer step comes near; an exit ever
 
 template <int LV> struct Lds3 {
     static constexpr int RK_DOUBLES = RK_UNI * rk_maxr(LV) + RK_LANE * 64;
-    static constexpr int HIST_DOUBLES = RK_MAXR / 2;
+    static constexpr int HIST_DOUBLES = RK_MAXR;
     static constexpr int X0 = RK_DOUBLES + HIST_DOUBLES;
     static constexpr int IO_DOUBLES = (int)((sizeof(wts::StepIO) + 7) / 8);
     static_assert(IO_DOUBLES <= X_SLOTS * 64, "StepIO aliases the exchange slots");
@@ -207,16 +207,17 @@ __device__ __forceinline__ void run_item3(ArgPtr pa, const Lane &L, double *lds,
     ArgPtr a = fresh(pa);
     const int n_zones = a->n, R = a->R;
     const int lane = threadIdx.x & 63, seg = lane / n_zones;
-    const int64_t r_first = (int64_t)group * R;
-    const int64_t r_end = a->q_ctrl ? a->N : a->r1;
-    const int64_t r = r_first + seg;
-    const bool present = (seg < R) && (r < r_end);
+    const int64_t q_first = (int64_t)group * R;
+    const int64_t q_end = a->q_ctrl ? a->N : a->r1;
+    const bool present = (seg < R) && (q_first + seg < q_end);
+    const int64_t r = present ? (int64_t)a->perm[q_first + seg] : 0;
     const int64_t idx = r * n_zones + L.z;
     const double dt = a->dt;
     const int step_limit = a->step_limit, sens_on = a->sens.on, plc_on = a->sens.plc_on;
     const bool want_diag = a->wave_diag != nullptr;
     const RKStore ks = {lds + seg, lds + RK_UNI * rk_maxr(LV) + lane, rk_maxr(LV)};
     int *hist0 = reinterpret_cast<int *>(lds + M::RK_DOUBLES);
+    int *rix = hist0 + RK_MAXR;
     double *X = lds + M::X0;
     int *xbad = reinterpret_cast<int *>(lds + M::BAD0);
     double *part = lds + M::PART0;                     // part[(kind * 3 + species) * RK_MAXR + seg]
@@ -249,6 +250,7 @@ __device__ __forceinline__ void run_item3(ArgPtr pa, const Lane &L, double *lds,
             RK k0; load_reactor(a->par, a->bc, a->N, r, n_zones, k0); mask_reactor_for_lane(L, k0);
             park_reactor(ks, k0);
             if (sens_on && L.z == 0) hist0[seg] = a->sens.hist_value ? a->sens.hist_pos[r] : 0;
+            if (L.z == 0) rix[seg] = (int)r;
         }
     }
     __syncthreads();
@@ -1013,13 +1015,13 @@ __device__ __forceinline__ void run_item3(ArgPtr pa, const Lane &L, double *lds,
                 if (!L.has_hi) io.tap[2 * sp + 1][seg] = (float)y0;
             }
             __syncthreads();
-            if (sp == SCL) wts::suite_step(b->sens, io, r_first, R, hist0, k);          // read_all_sensors
+            if (sp == SCL) wts::suite_step(b->sens, io, rix, R, hist0, k);              // read_all_sensors
             if (plc_on) {
                 const int gs = b->first_step + step0 + k;
                 const bool scan = ((gs + 1) % b->sens.scan_every == 0) || (gs + 1 == b->call_steps);
                 __syncthreads();
                 if (sp == SCL && lane < R && io.stepped[lane]) {          // one lane per reactor
-                    const int64_t rr = r_first + lane;
+                    const int64_t rr = rix[lane];
                     const double lt = b->sens.pack.loop_time[rr];
                     if (scan) {
                         wtp::pack_inputs(b->sens.pack, rr, &io.val[0][lane], &io.fault[0][lane], wts::RMAX, lt);   // update_modbus_inputs
@@ -1096,7 +1098,7 @@ __global__ __launch_bounds__(192) void triad_kernel(const StepArgs a)
     bool exchanged = true;
     int group;
     if (queue) {
-        if (sp == 0) { group = queue_next(a, -1, exchanged); if ((threadIdx.x & 63) == 0) { hand[0] = group; hand[1] = exchanged ? 1 : 0; } }
+        if (sp == 0) { group = queue_next(a, -1, false, exchanged); if ((threadIdx.x & 63) == 0) { hand[0] = group; hand[1] = exchanged ? 1 : 0; } }
         __syncthreads();
         group = hand[0]; exchanged = hand[1] != 0;
     } else {
@@ -1132,7 +1134,7 @@ __global__ __launch_bounds__(192) void triad_kernel(const StepArgs a)
                     }
                 }
             }
-            group = queue_next(a, more ? group : -1, exchanged);
+            group = queue_next(a, more ? group : -1, false, exchanged);
             if ((threadIdx.x & 63) == 0) { hand[0] = group; hand[1] = exchanged ? 1 : 0; }
         }
         __syncthreads();

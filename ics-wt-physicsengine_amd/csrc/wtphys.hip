@@ -6,6 +6,7 @@
 #include "wt_triad.hpp"
 #endif
 #include "wt_diag.hpp"
+#include "wt_place.hpp"
 #include "../../include/wtphys.h"
 
 #include <cmath>
@@ -53,6 +54,10 @@ struct wt_ensemble {
     int32_t *stats = nullptr;
     int64_t *wave_diag = nullptr; // optional per-wavefront diagnostics (wt_ensemble_enable_wave_diag)
     double *bad_T = nullptr;      // [N] temperature named by the reference's ValueError
+    // placement of reactors into wavefront-groups (wt_place.hpp): slot -> reactor, cost history, sort scratch
+    int32_t *perm = nullptr, *cost = nullptr, *place_hist = nullptr;
+    int placement = WT_PLACE_ADAPTIVE;
+    int64_t cost_steps = 0;       // outer steps the cost history covers
     // device-side work queue of the default schedule (wt_device.hpp): control words, FIFO slots, next step per group
     int32_t *q_ctrl = nullptr; unsigned long long *q_slots = nullptr; int32_t *q_next = nullptr;
     int q_cap = 0, q_workers = 0;
@@ -99,6 +104,7 @@ wt::StepArgs make_args(const wt_ensemble *h, double dt, int n_steps, int first_s
     a.pH = h->pH; a.Cl = h->Cl; a.T = h->T; a.time = h->time; a.flow = h->flow;
     a.dH = h->dH; a.dRho = h->dRho; a.dK = h->dK;
     a.status = h->status; a.stats = h->stats; a.wave_diag = h->wave_diag; a.bad_T = h->bad_T;
+    a.perm = h->perm; a.cost = (h->placement == WT_PLACE_ADAPTIVE) ? h->cost : nullptr;
     a.dt = dt; a.n_steps = n_steps; a.first_step = first_step; a.call_steps = call_steps; a.step_limit = h->step_limit;
     a.q_ctrl = nullptr; a.q_slots = nullptr; a.q_next = nullptr; a.q_cap = 0; a.item_steps = n_steps; a.n_groups = (int)h->n_groups;
     a.trace = h->trace; a.trace_cap = h->trace_cap;
@@ -310,6 +316,9 @@ int wt_ensemble_create(int64_t n_reactors, int n_zones, int device, const double
     ALLOC(h->status, sizeof(uint32_t) * N);
     ALLOC(h->stats, sizeof(int32_t) * 5 * N);
     ALLOC(h->bad_T, sizeof(double) * N);
+    ALLOC(h->perm, sizeof(int32_t) * N);
+    ALLOC(h->cost, sizeof(int32_t) * N);
+    ALLOC(h->place_hist, sizeof(int32_t) * wtpl::BINS * ((N + wtpl::CHUNK - 1) / wtpl::CHUNK));
     h->n_groups = (n_reactors + h->R - 1) / h->R;
     if (h->n_groups > 0x3fffffff) { cleanup(); return fail(WT_E_ARG, "too many reactors for one ensemble"); }
     h->q_cap = (int)(2 * h->n_groups + 64);
@@ -331,6 +340,11 @@ int wt_ensemble_create(int64_t n_reactors, int n_zones, int device, const double
     if (e == hipSuccess) e = hipMemsetAsync(h->time, 0, sizeof(double) * N, h->stream);
     if (e == hipSuccess) e = hipMemsetAsync(h->flow, 0, sizeof(double) * N, h->stream);
     if (e == hipSuccess) e = hipMemsetAsync(h->bad_T, 0, sizeof(double) * N, h->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(h->cost, 0, sizeof(int32_t) * N, h->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(wtpl::iota_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, h->stream, h->perm, (int64_t)N);
+        e = hipGetLastError();
+    }
     if (e == hipSuccess) e = hipMemsetAsync(h->q_ctrl, 0, sizeof(int32_t) * wt::Q_WORDS, h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     if (e != hipSuccess) { cleanup(); return fail(WT_E_HIP, std::string("upload: ") + hipGetErrorString(e)); }
@@ -345,7 +359,7 @@ int wt_ensemble_destroy(wt_ensemble *h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->trace) (void)hipFree(h->trace);
     void *ptrs[] = {h->par, h->bc, h->pH, h->Cl, h->T, h->time, h->flow, h->dH, h->dRho, h->dK, h->status, h->stats, h->wave_diag,
-                    h->bad_T, h->q_ctrl, h->q_slots, h->q_next};
+                    h->bad_T, h->q_ctrl, h->q_slots, h->q_next, h->perm, h->cost, h->place_hist};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (int s = 0; s < WT_MAX_STREAMS; ++s) {
         if (h->sub_stream[s]) { (void)hipStreamSynchronize(h->sub_stream[s]); (void)hipStreamDestroy(h->sub_stream[s]); }
@@ -416,11 +430,22 @@ int wt_ensemble_step(wt_ensemble *h, double dt, int n_steps, int fused)
     const int chunk = fused ? (h->chunk_steps > 0 ? h->chunk_steps : n_steps) : 1;
     if (h->wave_diag)
         HIP_TRY(hipMemsetAsync(h->wave_diag, 0, sizeof(int64_t) * wt::WT_DIAG_SLOTS * (size_t)h->n_groups, h->stream));
+    struct CountSteps { wt_ensemble *h; int n; ~CountSteps() { if (h->placement == WT_PLACE_ADAPTIVE) h->cost_steps += n; } } count_steps{h, n_steps};
     if (h->sched_mode == WT_SCHED_QUEUE) {
         // One launch of q_workers worker wavefronts (more than one only if the call is so long that the queue's
         // 32-bit tickets -- one per work item -- could run out: groups x items per launch stays below 2^30).
         const int W = h->q_workers > 0 ? h->q_workers : 1;
         const int item = queue_item_steps(n_steps);
+        // Reactors of similar solver cost share a wavefront: once the cost history covers enough outer steps to tell
+        // a reactor's regime from a burst, the slots are re-dealt in cost order (three small kernels, no sync).
+        if (h->placement == WT_PLACE_ADAPTIVE && h->cost_steps >= WT_PLACE_MIN_STEPS) {
+            const int blocks = (int)((h->N + wtpl::CHUNK - 1) / wtpl::CHUNK);
+            const wtpl::PlaceArgs pa{h->N, h->cost, (int)(h->cost_steps > 0x7fffffff ? 0x7fffffff : h->cost_steps), h->place_hist, h->perm};
+            hipLaunchKernelGGL(wtpl::place_count_kernel, dim3(blocks), dim3(wtpl::BINS), 0, h->stream, pa);
+            hipLaunchKernelGGL(wtpl::place_scan_kernel, dim3(1), dim3(wtpl::BINS), 0, h->stream, pa, blocks);
+            hipLaunchKernelGGL(wtpl::place_scatter_kernel, dim3(blocks), dim3(wtpl::BINS), 0, h->stream, pa);
+            h->cost_steps = 0;
+        }
         int64_t tickets = (int64_t)1 << 30;
         if (const char *e = getenv("WT_Q_TICKETS")) if (atoll(e) > 0) tickets = atoll(e);     // test knob: force the split
         int64_t per_launch = tickets / h->n_groups * item;
@@ -657,6 +682,32 @@ int wt_ensemble_diagnostics(wt_ensemble *h, double *out)
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(out, h->diag_out, bytes, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
+    return WT_OK;
+}
+
+int wt_ensemble_set_placement(wt_ensemble *h, int mode)
+{
+    if (!h) return fail(WT_E_ARG, "NULL handle");
+    if (mode != WT_PLACE_IDENTITY && mode != WT_PLACE_ADAPTIVE) return fail(WT_E_ARG, "placement mode must be WT_PLACE_IDENTITY or WT_PLACE_ADAPTIVE");
+    HIP_TRY(hipSetDevice(h->device));
+    if (mode == WT_PLACE_IDENTITY)
+        hipLaunchKernelGGL(wtpl::iota_kernel, dim3((unsigned)((h->N + 255) / 256)), dim3(256), 0, h->stream, h->perm, h->N);
+    HIP_TRY(hipMemsetAsync(h->cost, 0, sizeof(int32_t) * (size_t)h->N, h->stream));
+    HIP_TRY(hipGetLastError());
+    h->placement = mode;
+    h->cost_steps = 0;
+    return WT_OK;
+}
+
+int wt_ensemble_get_placement(wt_ensemble *h, int *mode, int32_t *perm)
+{
+    if (!h) return fail(WT_E_ARG, "NULL handle");
+    if (mode) *mode = h->placement;
+    if (perm) {
+        HIP_TRY(hipSetDevice(h->device));
+        HIP_TRY(hipMemcpyAsync(perm, h->perm, sizeof(int32_t) * (size_t)h->N, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+    }
     return WT_OK;
 }
 

@@ -123,6 +123,19 @@ int wt_ensemble_queue_error(wt_ensemble *h, int *error);
  * together (they wait for the slowest of them), which is what makes the end of an outer step a
  * wavefront-uniform point for the sensor suite and the PLC scan.  Results never depended on it. */
 int wt_ensemble_set_sync(wt_ensemble *h, int sync_outer);
+/* Placement of reactors into wavefronts.  Reactors never interact, so which of them share a wavefront changes no
+ * result bit -- but a wavefront costs what its slowest reactor costs.  WT_PLACE_ADAPTIVE (default): once the cost
+ * history (the solver's RHS evaluations per reactor) covers WT_PLACE_MIN_STEPS outer steps, the next wt_ensemble_step
+ * call re-deals the wavefront slots in order of cost (device-side stable counting sort on the handle's stream, no
+ * synchronisation) and restarts the history.  WT_PLACE_IDENTITY: reactor r sits in slot r, as in round 1.
+ * wt_ensemble_get_placement: current mode and slot -> reactor table [N] (either pointer may be NULL; the table
+ * synchronises the stream).  No counterpart in the reference (one reactor per process). */
+#define WT_PLACE_IDENTITY 0
+#define WT_PLACE_ADAPTIVE 1
+#define WT_PLACE_MIN_STEPS 32
+int wt_ensemble_set_placement(wt_ensemble *h, int mode);
+int wt_ensemble_get_placement(wt_ensemble *h, int *mode, int32_t *perm);
+
 /* Guard the reference lacks.  Where the solution slides along a discontinuity of the RHS (the
  * 8 degC density branch, spatial.py:177-189, under strong heat loss) scipy's Radau takes millions
  * of internal steps for one outer step; the reference would grind through them for hours.  A

@@ -189,6 +189,45 @@ def test_results_do_not_depend_on_the_launch_schedule(gpu, wt, n):
         ens.close()
 
 
+@pytest.mark.parametrize("n", [4, 8, 20])
+def test_placement_changes_no_bit(gpu, wt, n):
+    """Reactors of similar solver cost are dealt into the same wavefronts (wt_place.hpp) once 32 outer steps of
+    counters are in.  The slot table is then a permutation in order of cost, and state, status, solver counters,
+    sensor readings, register images and the commanded boundary are those of the fixed placement, bit for bit."""
+    N, calls, steps = 3000, 3, 40
+    cols, bc = wt.make_ensemble(N, seed=2024)
+    def run(adaptive):
+        ens = wt.ReactorEnsemble(cols, n_zones=n); ens.set_boundary(bc)
+        ens.set_placement(adaptive)
+        ens.enable_sensors(seed=9); ens.enable_plant_io()
+        ens.write_commands(bc[4], bc[6], bc[0])             # the masters' setpoints = the synthetic boundary (as float32)
+        cost = np.zeros(N)
+        for c in range(calls):
+            es = ens.step(1.0, n_steps=steps)
+            if c == 0:
+                first_call_perm = ens.placement()[1].copy()
+        for k in range(8):
+            es = ens.step(1.0, n_steps=1); cost += ens.solver_stats()[:, 0]
+        mode, perm = ens.placement()
+        out = (es.pH, es.chlorine, es.temperature, es.time, es.status, es.H_concentration, es.density, es.chlorine_decay_rate,
+               ens.solver_stats(), *ens.sensor_readings(), *ens.input_image(), ens.boundary())
+        ens.close()
+        return out, mode, perm, first_call_perm, cost
+    ref, mode0, perm0, _, _ = run(False)
+    got, mode1, perm1, first, cost = run(True)
+    assert mode0 is False and np.array_equal(perm0, np.arange(N))
+    assert mode1 is True and np.array_equal(first, np.arange(N))            # nothing to go by during the first call
+    assert np.array_equal(np.sort(perm1), np.arange(N)) and not np.array_equal(perm1, np.arange(N))
+    # the table is in order of the cost history it was dealt from; the costs persist, so later costs follow it closely
+    ordered = cost[perm1]
+    assert np.corrcoef(np.arange(N), ordered)[0, 1] > 0.5
+    R = 64 // n
+    m = (N // R) * R
+    assert ordered[:m].reshape(-1, R).max(1).sum() < 0.97 * cost[:m].reshape(-1, R).max(1).sum()
+    for a_, b_ in zip(ref, got):
+        assert np.array_equal(a_, b_, equal_nan=True)
+
+
 def test_very_long_calls_are_split_without_a_trace(gpu, wt, monkeypatch):
     """The queue's tickets are 32-bit: a call that would need more than 2^30 of them is cut into several launches
     (wtphys.hip).  With the ticket budget turned down (WT_Q_TICKETS, test knob) a 23-step call becomes eight launches
