@@ -1583,7 +1583,7 @@ __global__ __launch_bounds__(64) void step_kernel(const StepArgs a)
             // items this group has behind it against the ensemble's average
             const long long done = __hip_atomic_fetch_add(a.q_ctrl + Q_DONE, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
             const long long mine = (step0 + cnt + a.item_steps - 1) / a.item_steps;
-            hold = (mine * a.n_groups < done) ? 1 : 0;
+            hold = (mine * a.n_groups < done) ? 1 : 0;     // (one item more or less of slack either way: measured worse)
             if (a.trace) {
                 const int slot = __hip_atomic_fetch_add(a.q_ctrl + Q_TRACE, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (slot < a.trace_cap) {

@@ -430,7 +430,8 @@ int wt_ensemble_step(wt_ensemble *h, double dt, int n_steps, int fused)
     const int chunk = fused ? (h->chunk_steps > 0 ? h->chunk_steps : n_steps) : 1;
     if (h->wave_diag)
         HIP_TRY(hipMemsetAsync(h->wave_diag, 0, sizeof(int64_t) * wt::WT_DIAG_SLOTS * (size_t)h->n_groups, h->stream));
-    struct CountSteps { wt_ensemble *h; int n; ~CountSteps() { if (h->placement == WT_PLACE_ADAPTIVE) h->cost_steps += n; } } count_steps{h, n_steps};
+    // (the stream schedule feeds the cost history too; only the queue schedule re-deals)
+    struct CountSteps { wt_ensemble *h; int n; ~CountSteps() { if (h->placement == WT_PLACE_ADAPTIVE && h->sched_mode != WT_SCHED_QUEUE) h->cost_steps += n; } } count_steps{h, n_steps};
     if (h->sched_mode == WT_SCHED_QUEUE) {
         // One launch of q_workers worker wavefronts (more than one only if the call is so long that the queue's
         // 32-bit tickets -- one per work item -- could run out: groups x items per launch stays below 2^30).
@@ -438,25 +439,30 @@ int wt_ensemble_step(wt_ensemble *h, double dt, int n_steps, int fused)
         const int item = queue_item_steps(n_steps);
         // Reactors of similar solver cost share a wavefront: once the cost history covers enough outer steps to tell
         // a reactor's regime from a burst, the slots are re-dealt in cost order (three small kernels, no sync).
-        if (h->placement == WT_PLACE_ADAPTIVE && h->cost_steps >= WT_PLACE_MIN_STEPS) {
+        int64_t min_steps = WT_PLACE_MIN_STEPS;
+        if (const char *e = getenv("WT_PLACE_MIN")) if (atoll(e) > 0) min_steps = atoll(e);    // tuning knob (tools/)
+        auto redeal = [&]() {
+            if (h->placement != WT_PLACE_ADAPTIVE || h->cost_steps < min_steps) return;
             const int blocks = (int)((h->N + wtpl::CHUNK - 1) / wtpl::CHUNK);
             const wtpl::PlaceArgs pa{h->N, h->cost, (int)(h->cost_steps > 0x7fffffff ? 0x7fffffff : h->cost_steps), h->place_hist, h->perm};
             hipLaunchKernelGGL(wtpl::place_count_kernel, dim3(blocks), dim3(wtpl::BINS), 0, h->stream, pa);
             hipLaunchKernelGGL(wtpl::place_scan_kernel, dim3(1), dim3(wtpl::BINS), 0, h->stream, pa, blocks);
             hipLaunchKernelGGL(wtpl::place_scatter_kernel, dim3(blocks), dim3(wtpl::BINS), 0, h->stream, pa);
             h->cost_steps = 0;
-        }
+        };
         int64_t tickets = (int64_t)1 << 30;
         if (const char *e = getenv("WT_Q_TICKETS")) if (atoll(e) > 0) tickets = atoll(e);     // test knob: force the split
         int64_t per_launch = tickets / h->n_groups * item;
         if (per_launch < item) per_launch = item;
         for (int64_t done = 0; done < n_steps; done += per_launch) {
             const int cnt = (int)((n_steps - done < per_launch) ? n_steps - done : per_launch);
+            redeal();
             wt::StepArgs a = make_args(h, dt, cnt, (int)done, n_steps, chunk);
             a.q_ctrl = h->q_ctrl; a.q_slots = h->q_slots; a.q_next = h->q_next; a.q_cap = h->q_cap; a.item_steps = item;
             wt::QueueResetArgs qr{h->q_ctrl, h->q_slots, h->q_next, (int)h->n_groups, h->q_cap};
             hipLaunchKernelGGL(wt::queue_reset_kernel, dim3((unsigned)((h->q_cap + 255) / 256)), dim3(256), 0, h->stream, qr);
             launch_step(h, a, (unsigned)W, h->stream);
+            if (h->placement == WT_PLACE_ADAPTIVE) h->cost_steps += cnt;
         }
         HIP_TRY(hipGetLastError());
         return WT_OK;
