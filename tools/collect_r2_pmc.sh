@@ -29,6 +29,6 @@ python3 bench.py --no-cpu-baseline --reactors 12500 --sensors > $O/bench_sensors
 python3 bench.py --no-cpu-baseline --reactors 12500 > $O/bench_12500.json 2>> $O/err.log
 python3 bench.py --no-cpu-baseline --zones 4 > $O/bench_n4.json 2>> $O/err.log
 python3 bench.py --no-cpu-baseline --zones 20 > $O/bench_n20.json 2>> $O/err.log
-python3 bench.py --no-cpu-baseline --reactors 100000 --steps 100 --warmup 20 > $O/bench_100k.json 2>> $O/err.log
+python3 bench.py --no-cpu-baseline --reactors 100000 --steps 100 --warmup 40 > $O/bench_100k.json 2>> $O/err.log
 python3 bench.py --no-cpu-baseline --streams 4 > $O/bench_streams4.json 2>> $O/err.log
 echo done
