@@ -209,6 +209,8 @@ def test_placement_changes_no_bit(gpu, wt, n):
         for k in range(8):
             es = ens.step(1.0, n_steps=1); cost += ens.solver_stats()[:, 0]
         mode, perm = ens.placement()
+        ens.set_schedule(3, 4)                               # the stream schedule walks the same slot table
+        es = ens.step(1.0, n_steps=9)
         out = (es.pH, es.chlorine, es.temperature, es.time, es.status, es.H_concentration, es.density, es.chlorine_decay_rate,
                ens.solver_stats(), *ens.sensor_readings(), *ens.input_image(), ens.boundary())
         ens.close()
