@@ -1,5 +1,5 @@
 """Parity report: HIP path vs the reference's golden trajectories and vs the CPU oracle on
-the full-size bench ensembles.  Writes profiles/r1/parity_report.json (run on the GPU box)."""
+the full-size bench ensembles.  Writes profiles/r2/parity_report.json (run on the GPU box)."""
 import glob, importlib, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tests"))
