@@ -82,6 +82,127 @@ constexpr double K_ARR = -0x1.5248ea03d1718p+12;   // -(45000/8.314)  thermodyna
 constexpr double INV_TREF = 0x1.bf1da5ca77e69p-9;  // 1/293.15
 } // namespace rc
 
+
+// ---------------------------------------------------------------- fp64 constants of the RHS as scalar loads
+// A VALU instruction on gfx950 cannot carry a 64-bit literal: every fp64 constant that is not an inline constant
+// reaches it through an SGPR pair, i.e. two s_mov_b32 -- and with one wavefront per SIMD a scalar move costs the
+// same issue slot as an fp64 FMA (measured: tools/ubench/issue.hip).  The exponential's polynomial alone is ten
+// such pairs per inlined copy of the RHS.  So the constants of a section sit in the kernel-argument block
+// (filled by the host, wtphys.hip: make_args) and are fetched at the top of the section with s_load_dwordx16:
+// eight constants per issue slot instead of half a constant.
+// exp / exp10 follow OCML's algorithm with OCML's coefficients (checked bit for bit against the library's on the
+// device over 4M arguments each: tools/ubench/expcheck.hip), so nothing changes numerically.
+typedef double d8 __attribute__((ext_vector_type(8)));
+struct alignas(64) KTab {
+    // section P -- pH properties: 24 doubles
+    double pc[10];                                                   // exp polynomial, degree-11 term first
+    double log2_10, lg2_hi, lg2_lo, ln10_hi, ln10_lo, t_hi, t_lo;    // exp10 argument reduction and range
+    double c2303, ln10, c002, pad_p[4];
+    // section T -- temperature properties: 32 doubles
+    double tc[10];
+    double log2e, ln2_hi, ln2_lo, e_hi, e_lo;                        // exp argument reduction and range
+    double k_arr, inv_tref, c27315, c1em4;                           // Arrhenius (thermodynamics.py:160-193)
+    double rho_max, rho_an, rho20, rho_sl, c20, c8, c100;            // density branches (spatial.py:177-189), T range
+    double pad_t[6];
+};
+static_assert(sizeof(KTab) == 56 * 8, "KTab layout");
+
+__host__ __device__ constexpr KTab default_ktab()
+{
+    KTab k{};
+    constexpr double c[10] = {0x1.ade156a5dcb37p-26, 0x1.28af3fca7ab0cp-22, 0x1.71dee623fde64p-19, 0x1.a01997c89e6b0p-16,
+                              0x1.a01a014761f6ep-13, 0x1.6c16c1852b7b0p-10, 0x1.1111111122322p-7, 0x1.55555555502a1p-5,
+                              0x1.5555555555511p-3, 0x1.000000000000bp-1};
+    for (int i = 0; i < 10; ++i) { k.pc[i] = c[i]; k.tc[i] = c[i]; }
+    k.log2_10 = 0x1.a934f0979a371p+1; k.lg2_hi = 0x1.34413509f79ffp-2; k.lg2_lo = -0x1.9dc1da994fd21p-59;
+    k.ln10_hi = 0x1.26bb1bbb55516p+1; k.ln10_lo = -0x1.f48ad494ea3e9p-53;
+    k.t_hi = 0x1.34413509f79ffp+8; k.t_lo = -0x1.439b746e36b52p+8;   // 10^x overflows above / is 0 below
+    k.c2303 = 2.303; k.ln10 = rc::LN10; k.c002 = 0.02;
+    k.log2e = 0x1.71547652b82fep+0; k.ln2_hi = 0x1.62e42fefa39efp-1; k.ln2_lo = 0x1.abc9e3b39803fp-56;
+    k.e_hi = 0x1.62e42fefa39efp+9; k.e_lo = -0x1.74910d52d3051p+9;
+    k.k_arr = rc::K_ARR; k.inv_tref = rc::INV_TREF; k.c27315 = 273.15; k.c1em4 = 0.0001;
+    k.rho_max = 999.97; k.rho_an = -0.008; k.rho20 = 998.2; k.rho_sl = -2.1e-4 * 998.2; k.c20 = 20.0; k.c8 = 8.0; k.c100 = 100.0;
+    return k;
+}
+
+// the constants a section works with, as plain doubles (SGPR pairs after the loads below)
+struct KP { double c[10], log2_10, lg2_hi, lg2_lo, ln10_hi, ln10_lo, t_hi, t_lo, c2303, ln10, c002; };
+struct KT { double c[10], log2e, ln2_hi, ln2_lo, e_hi, e_lo, k_arr, inv_tref, c27315, c1em4, rho_max, rho_an, rho20, rho_sl, c20, c8, c100; };
+
+__host__ __device__ constexpr KP kp_of(const KTab &t)
+{
+    KP k{};
+    for (int i = 0; i < 10; ++i) k.c[i] = t.pc[i];
+    k.log2_10 = t.log2_10; k.lg2_hi = t.lg2_hi; k.lg2_lo = t.lg2_lo; k.ln10_hi = t.ln10_hi; k.ln10_lo = t.ln10_lo;
+    k.t_hi = t.t_hi; k.t_lo = t.t_lo; k.c2303 = t.c2303; k.ln10 = t.ln10; k.c002 = t.c002;
+    return k;
+}
+__host__ __device__ constexpr KT kt_of(const KTab &t)
+{
+    KT k{};
+    for (int i = 0; i < 10; ++i) k.c[i] = t.tc[i];
+    k.log2e = t.log2e; k.ln2_hi = t.ln2_hi; k.ln2_lo = t.ln2_lo; k.e_hi = t.e_hi; k.e_lo = t.e_lo;
+    k.k_arr = t.k_arr; k.inv_tref = t.inv_tref; k.c27315 = t.c27315; k.c1em4 = t.c1em4;
+    k.rho_max = t.rho_max; k.rho_an = t.rho_an; k.rho20 = t.rho20; k.rho_sl = t.rho_sl; k.c20 = t.c20; k.c8 = t.c8; k.c100 = t.c100;
+    return k;
+}
+
+typedef const __attribute__((address_space(4))) d8 *KVec;
+// three / four s_load_dwordx16 from the kernel-argument segment
+__device__ __forceinline__ KP load_kp(const __attribute__((address_space(4))) KTab *t)
+{
+    KVec q = (KVec)t;
+    const d8 a = q[0], b = q[1], c = q[2];
+    KP k;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) k.c[i] = a[i];
+    k.c[8] = b[0]; k.c[9] = b[1];
+    k.log2_10 = b[2]; k.lg2_hi = b[3]; k.lg2_lo = b[4]; k.ln10_hi = b[5]; k.ln10_lo = b[6]; k.t_hi = b[7];
+    k.t_lo = c[0]; k.c2303 = c[1]; k.ln10 = c[2]; k.c002 = c[3];
+    return k;
+}
+__device__ __forceinline__ KT load_kt(const __attribute__((address_space(4))) KTab *t)
+{
+    KVec q = (KVec)t + 3;
+    const d8 a = q[0], b = q[1], c = q[2], d = q[3];
+    KT k;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) k.c[i] = a[i];
+    k.c[8] = b[0]; k.c[9] = b[1];
+    k.log2e = b[2]; k.ln2_hi = b[3]; k.ln2_lo = b[4]; k.e_hi = b[5]; k.e_lo = b[6]; k.k_arr = b[7];
+    k.inv_tref = c[0]; k.c27315 = c[1]; k.c1em4 = c[2]; k.rho_max = c[3]; k.rho_an = c[4]; k.rho20 = c[5]; k.rho_sl = c[6]; k.c20 = c[7];
+    k.c8 = d[0]; k.c100 = d[1];
+    return k;
+}
+
+// e^t for the reduced argument t, times 2^dn (the tail both exponentials share)
+__device__ __forceinline__ double exp_tail(const double c[10], double t, double dn)
+{
+    double p = c[0];
+#pragma unroll
+    for (int i = 1; i < 10; ++i) p = __builtin_fma(t, p, c[i]);
+    p = __builtin_fma(t, p, 1.0);
+    p = __builtin_fma(t, p, 1.0);
+    return __builtin_amdgcn_ldexp(p, (int)dn);
+}
+__device__ __forceinline__ double exp_k(const KT &k, double x)
+{
+    const double dn = __builtin_rint(x * k.log2e);
+    const double t = __builtin_fma(-dn, k.ln2_lo, __builtin_fma(-dn, k.ln2_hi, x));
+    double z = exp_tail(k.c, t, dn);
+    z = (x > k.e_hi) ? __builtin_inf() : z;
+    return (x < k.e_lo) ? 0.0 : z;
+}
+__device__ __forceinline__ double exp10_k(const KP &k, double x)
+{
+    const double dn = __builtin_rint(x * k.log2_10);
+    const double u = __builtin_fma(-dn, k.lg2_lo, __builtin_fma(-dn, k.lg2_hi, x));
+    const double t = __builtin_fma(u, k.ln10_hi, u * k.ln10_lo);
+    double z = exp_tail(k.c, t, dn);
+    z = (x > k.t_hi) ? __builtin_inf() : z;
+    return (x < k.t_lo) ? 0.0 : z;
+}
+
 struct StepArgs {
     int64_t N;        // reactors in the ensemble (row stride of par / bc)
     int64_t r0, r1;   // stream schedule: this launch advances reactors [r0, r1); queue schedule: [0, N)
@@ -113,6 +234,7 @@ struct StepArgs {
     int q_cap, item_steps, n_groups;
     int64_t *trace; int trace_cap;   // optional item trace (tools/): worker, group, step0 | cnt << 32, start, end (100 MHz ticks)
     wts::SuiteArgs sens; // fused sensor suite + plant I/O (sens.on == 0: none)
+    KTab kt;             // fp64 constants of the RHS sections (scalar loads)
 };
 enum { Q_AVAIL = 0, Q_HEAD = 1, Q_TAIL = 2, Q_ERROR = 3, Q_TRACE = 4, Q_DONE = 5, Q_WORDS = 16 };
 
@@ -269,7 +391,7 @@ __device__ __forceinline__ void load_reactor(const double *par, const double *bc
     k.unsupp = (strat_mode == 2) ? P(12) : 1.0;      // ... and where it does not
     const double Q_in = B(0);
     k.Qv = (Q_in / 60.0) / V;                   // reactor.py:336
-    k.H_in = exp10(-B(1));                      // reactor.py:363
+    k.H_in = exp10_k(kp_of(default_ktab()), -B(1));   // reactor.py:363
     k.Cl_in = B(2); k.T_in = B(3);
     const double zone_volume_L = V / n;
     k.has_acid = B(4) > 0;
@@ -337,12 +459,12 @@ struct PropT { double kT, rho; bool bad; };
 
 // H = 10^-pH, buffering capacity beta (chemistry.py:400-437), HOCl/OCl- decay
 // factor (chemistry.py:483-523).
-__device__ __forceinline__ PropPH prop_pH(const RK &k, double pH)
+__device__ __forceinline__ PropPH prop_pH(const KP &c, const RK &k, double pH)
 {
 #pragma clang fp contract(off)
     PropPH p;
-    const double H = exp10(-pH);
-    const double beta_w = 2.303 * __builtin_fma(k.Kw, rcp(H), H);
+    const double H = exp10_k(c, -pH);
+    const double beta_w = c.c2303 * __builtin_fma(k.Kw, rcp(H), H);
     const double H2 = H * H;
     const double D = __builtin_fma(k.Ka1, H, H2) + k.Ka1Ka2;
     const double iD = rcp(D);
@@ -350,9 +472,9 @@ __device__ __forceinline__ PropPH prop_pH(const RK &k, double pH)
     const double mix = __builtin_fma(a0, a2, __builtin_fma(4 * a1, a2, a0 * a1));
     const double beta = __builtin_fma(k.cbeta, mix, beta_w);
     p.bpos = beta > 0;                           // reactor.py:358,367,375 guards: no pH change unless beta > 0
-    p.iw = p.bpos ? rcp(beta * rc::LN10) : 0.0;
+    p.iw = p.bpos ? rcp(beta * c.ln10) : 0.0;
     const double iHK = rcp(H + k.KaH);
-    p.phi = __builtin_fma(k.KaH * iHK, 0.02, H * iHK);
+    p.phi = __builtin_fma(k.KaH * iHK, c.c002, H * iHK);
     p.H = H;
     return p;
 }
@@ -360,17 +482,17 @@ __device__ __forceinline__ PropPH prop_pH(const RK &k, double pH)
 // Arrhenius decay rate (thermodynamics.py:160-193) with its [0,100] C check
 // (:146-157) and water density (spatial.py:177-189).  The density feeds the stratification switch, so it
 // is formed with the reference's roundings: products and sums separately, never fused.
-__device__ __forceinline__ PropT prop_T(double T)
+__device__ __forceinline__ PropT prop_T(const KT &c, double T)
 {
 #pragma clang fp contract(off)
     PropT p;
-    p.bad = (T < 0.0) || (T > 100.0);
-    const double ex = rc::K_ARR * (rcp(T + 273.15) - rc::INV_TREF);
-    p.kT = 0.0001 * exp(ex);
+    p.bad = (T < 0.0) || (T > c.c100);
+    const double ex = c.k_arr * (rcp(T + c.c27315) - c.inv_tref);
+    p.kT = c.c1em4 * exp_k(c, ex);
     const double d = T - 4.0;
-    const double cold = 999.97 + (-0.008 * (d * d));
-    const double warm = 998.2 + ((-2.1e-4 * 998.2) * (T - 20.0));
-    p.rho = (T <= 8.0) ? cold : warm;
+    const double cold = c.rho_max + (c.rho_an * (d * d));
+    const double warm = c.rho20 + (c.rho_sl * (T - c.c20));
+    p.rho = (T <= c.c8) ? cold : warm;
     return p;
 }
 
@@ -418,10 +540,10 @@ __device__ __forceinline__ void rhs_rows(const Lane &L, const RK &k, double H, d
 }
 
 template <bool ROW>
-__device__ __forceinline__ bool rhs_full(const Lane &L, const RK &k, const double y[3], double f[3])
+__device__ __forceinline__ bool rhs_full(const Lane &L, const KP &cp, const KT &ct, const RK &k, const double y[3], double f[3])
 {
-    const PropPH pp = prop_pH(k, y[SPH]);
-    const PropT pt = prop_T(y[STT]);
+    const PropPH pp = prop_pH(cp, k, y[SPH]);
+    const PropT pt = prop_T(ct, y[STT]);
     rhs_rows<ROW>(L, k, pp.H, pp.iw, pp.bpos, pt.kT * pp.phi, pt.rho, y[SCL], y[STT], f);
     return pt.bad;
 }
@@ -689,15 +811,15 @@ __device__ __forceinline__ double sel3(double x0, double x1, double x2, int idx)
 
 // Three colour passes of one species.  Results come back indexed by neighbour offset:
 // out.D[q][r] is the change of this lane's row q when the zone at offset r-1 was perturbed.
-template <bool ROW, int SP>
-__device__ __forceinline__ void fd_species_pass(const Lane &L, const RK &k, const double y[3], const double f[3],
+template <bool ROW, int SP, class KC>
+__device__ __forceinline__ void fd_species_pass(const Lane &L, const KC &kc, const RK &k, const double y[3], const double f[3],
                                                 const ZoneProps &b, double hcol, bool colmask, FdCols &out, bool &bad, double &badval)
 {
     const double ypert = y[SP] + hcol;
     ZoneProps p = b;
-    if constexpr (SP == SPH) { const PropPH q = prop_pH(k, ypert); p.H = q.H; p.iw = q.iw; p.phi = q.phi; p.bpos = q.bpos; }
+    if constexpr (SP == SPH) { const PropPH q = prop_pH(kc, k, ypert); p.H = q.H; p.iw = q.iw; p.phi = q.phi; p.bpos = q.bpos; }
     if constexpr (SP == STT) {
-        const PropT q = prop_T(ypert); p.kT = q.kT; p.rho = q.rho;
+        const PropT q = prop_T(kc, ypert); p.kT = q.kT; p.rho = q.rho;
         if (colmask && q.bad && !bad) { bad = true; badval = ypert; }   // the reference raises on this perturbed column
     }
     const int zm = L.z % 3;
@@ -770,15 +892,15 @@ __device__ __forceinline__ double fd_step(double y, double fac, double ysc)
 // One species' columns: perturb, reduce, optional retry, factor update.  Leaves
 // the finished difference quotients of this species' columns in `cols.D`
 // (already divided by the column's h).
-template <bool ROW, int SP>
-__device__ __forceinline__ void num_jac_species(const Lane &L, const RK &k, const double y[3], const double f[3],
+template <bool ROW, int SP, class KC>
+__device__ __forceinline__ void num_jac_species(const Lane &L, const KC &kc, const RK &k, const double y[3], const double f[3],
                                                 const ZoneProps &b, double &fac, FdCols &cols, bool &bad, double &badval)
 {
     const double fs = (f[SP] >= 0) ? 1.0 : -1.0;
     const double ysc = fs * fmax(ATOL, fabs(y[SP]));
     double h = fd_step(y[SP], fac, ysc);
     while (h == 0) { fac *= 10; h = fd_step(y[SP], fac, ysc); }    // common.py:327-330
-    fd_species_pass<ROW, SP>(L, k, y, f, b, h, true, cols, bad, badval);
+    fd_species_pass<ROW, SP>(L, kc, k, y, f, b, h, true, cols, bad, badval);
     double maxd, scl;
     fd_col_reduce<ROW, SP>(L, cols, maxd, scl);
     const bool small = maxd < rc::NJ_REJECT * scl;                  // common.py:341
@@ -786,7 +908,7 @@ __device__ __forceinline__ void num_jac_species(const Lane &L, const RK &k, cons
         const double nf = 10 * fac;
         const double hn = fd_step(y[SP], nf, ysc);
         FdCols c2;
-        fd_species_pass<ROW, SP>(L, k, y, f, b, hn, small, c2, bad, badval);
+        fd_species_pass<ROW, SP>(L, kc, k, y, f, b, hn, small, c2, bad, badval);
         double md2, sc2;
         fd_col_reduce<ROW, SP>(L, c2, md2, sc2);
         const bool upd = small && (maxd * sc2 < md2 * scl);         // common.py:354
@@ -813,25 +935,43 @@ __device__ __forceinline__ void num_jac_species(const Lane &L, const RK &k, cons
     fac = fmax(fac, rc::NJ_MINF);
 }
 
-template <bool ROW>
-__device__ __forceinline__ void num_jac(const Lane &L, const RK &k, const double y[3], const double f[3],
+// The three species' passes are sections like those of rhs_points: each fetches the constants it works with.
+// KTP: pointer to the constant table (kernel-argument segment in the step kernel).
+template <bool ROW, class KTP>
+__device__ __forceinline__ void num_jac(const Lane &L, const RKStore &ks, KTP ktab, const double y[3], const double f[3],
                                         double fac[3], bool &have_fac, Jac &J, bool &bad, double &badval)
 {
     if (!have_fac) { fac[0] = fac[1] = fac[2] = rc::NJ_F0; have_fac = true; }
-    const PropPH bpp = prop_pH(k, y[SPH]);
-    const PropT bpt = prop_T(y[STT]);
-    const ZoneProps b = {bpp.H, bpp.iw, bpp.phi, bpt.kT, bpt.rho, bpp.bpos};
     FdCols cols;
-    num_jac_species<ROW, SPH>(L, k, y, f, b, fac[SPH], cols, bad, badval);
+    ZoneProps b;
+    {
+        const KT ct = load_kt(ktab());
+        const PropT bpt = prop_T(ct, y[STT]);
+        b.kT = bpt.kT; b.rho = bpt.rho;
+    }
+    {
+        const KP cp = load_kp(ktab());
+        const RK k = fetch_reactor(ks);
+        const PropPH bpp = prop_pH(cp, k, y[SPH]);
+        b.H = bpp.H; b.iw = bpp.iw; b.phi = bpp.phi; b.bpos = bpp.bpos;
+        num_jac_species<ROW, SPH>(L, cp, k, y, f, b, fac[SPH], cols, bad, badval);
 #pragma unroll
-    for (int r = 0; r < 3; ++r) J.pp[r] = cols.D[SPH][r];
-    J.cp = cols.D[SCL][1];
-    num_jac_species<ROW, SCL>(L, k, y, f, b, fac[SCL], cols, bad, badval);
+        for (int r = 0; r < 3; ++r) J.pp[r] = cols.D[SPH][r];
+        J.cp = cols.D[SCL][1];
+    }
+    {
+        const RK k = fetch_reactor(ks);
+        num_jac_species<ROW, SCL>(L, 0, k, y, f, b, fac[SCL], cols, bad, badval);
 #pragma unroll
-    for (int r = 0; r < 3; ++r) J.cc[r] = cols.D[SCL][r];
-    num_jac_species<ROW, STT>(L, k, y, f, b, fac[STT], cols, bad, badval);
+        for (int r = 0; r < 3; ++r) J.cc[r] = cols.D[SCL][r];
+    }
+    {
+        const KT ct = load_kt(ktab());
+        const RK k = fetch_reactor(ks);
+        num_jac_species<ROW, STT>(L, ct, k, y, f, b, fac[STT], cols, bad, badval);
 #pragma unroll
-    for (int r = 0; r < 3; ++r) { J.tt[r] = cols.D[STT][r]; J.pt[r] = cols.D[SPH][r]; J.ct[r] = cols.D[SCL][r]; }
+        for (int r = 0; r < 3; ++r) { J.tt[r] = cols.D[STT][r]; J.pt[r] = cols.D[SPH][r]; J.ct[r] = cols.D[SCL][r]; }
+    }
 }
 
 // ---------------------------------------------------------------- helpers
@@ -926,32 +1066,45 @@ template <int LV> struct LdsMap {
     static constexpr int TOTAL = RK_DOUBLES + HIST_DOUBLES + TAIL_DOUBLES;
 };
 
+// The argument block has ~80 pointers; held in SGPRs across the solver loop they would crowd out the loop's own
+// scalars (the compiler hoists kernel-argument loads to the top of the kernel and then spills them).  Each section
+// of a work item therefore re-reads what it needs from the kernel-argument segment through a pointer the
+// optimiser cannot see through, which ends the live ranges at the section's end.
+typedef const __attribute__((address_space(4))) StepArgs *ArgPtr;
+__device__ __forceinline__ ArgPtr fresh(ArgPtr p)
+{
+    asm volatile("" : "+s"(p));
+    return p;
+}
+
 // ---- device-side work queue: FIFO of wavefront-groups that are ready for their next item (wave-uniform calls) ----
 // Tickets 0 .. n_groups-1 are the groups themselves, last group first (every group starts ready; the slots are dealt in
 // order of solver cost, so the expensive groups are the ones that must not start late); ticket n_groups + p is the
 // p-th push.
 // Q_AVAIL counts published, unclaimed entries, so a claimed ticket is always (about to be) written: the only wait
 // is for a pusher that sits between its tail increment and its slot store.
-__device__ __forceinline__ int queue_resolve(const StepArgs &a, int ticket)
+__device__ __forceinline__ int queue_resolve(ArgPtr a, int ticket)
 {
-    if (ticket < a.n_groups) return a.n_groups - 1 - ticket;
+    const int n_groups = a->n_groups;
+    if (ticket < n_groups) return n_groups - 1 - ticket;
     const unsigned long long want = (unsigned long long)(unsigned)(ticket + 1);
-    unsigned long long *slot = a.q_slots + (ticket - a.n_groups) % a.q_cap;
+    unsigned long long *slot = a->q_slots + (ticket - n_groups) % a->q_cap;
     for (int spin = 0; spin < (1 << 22); ++spin) {
         const unsigned long long w = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if ((w >> 32) == want) return (int)(w & 0xffffffffull);
         __builtin_amdgcn_s_sleep(2);
     }
-    __hip_atomic_store(a.q_ctrl + Q_ERROR, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // never seen; the host reports it
+    __hip_atomic_store(a->q_ctrl + Q_ERROR, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // never seen; the host reports it
     return -1;
 }
 
-__device__ __forceinline__ void queue_push(const StepArgs &a, int group)
+__device__ __forceinline__ void queue_push(ArgPtr a, int group)
 {
-    const int p = __hip_atomic_fetch_add(a.q_ctrl + Q_TAIL, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned long long w = ((unsigned long long)(unsigned)(a.n_groups + p + 1) << 32) | (unsigned)group;
-    __hip_atomic_store(a.q_slots + p % a.q_cap, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_fetch_add(a.q_ctrl + Q_AVAIL, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    int32_t *ctrl = a->q_ctrl;
+    const int p = __hip_atomic_fetch_add(ctrl + Q_TAIL, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long w = ((unsigned long long)(unsigned)(a->n_groups + p + 1) << 32) | (unsigned)group;
+    __hip_atomic_store(a->q_slots + p % a->q_cap, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(ctrl + Q_AVAIL, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // Next group for this worker, or -1 to retire.  own >= 0: the group just advanced still has steps to go; it goes to
@@ -963,14 +1116,22 @@ __device__ __forceinline__ void queue_push(const StepArgs &a, int group)
 // (Tried and dropped: letting groups whose items run long keep their worker, and dealing last launch's slow groups
 // first -- a group's cost comes in bursts when a reactor crosses a stratification switch, not as a persistent rate,
 // so neither shortens the tail of a short launch; see DESIGN.md.)
-__device__ __forceinline__ int queue_next(const StepArgs &a, int own, bool hold, bool &exchanged)
+__device__ __forceinline__ int queue_next(ArgPtr pa, int own, bool hold, bool &exchanged)
 {
+    ArgPtr a = fresh(pa);
     const bool lane0 = (threadIdx.x & 63) == 0;
     int ticket = -1;
     if (lane0 && !(own >= 0 && hold)) {
-        const int old = __hip_atomic_fetch_add(a.q_ctrl + Q_AVAIL, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (old > 0) ticket = __hip_atomic_fetch_add(a.q_ctrl + Q_HEAD, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else __hip_atomic_fetch_add(a.q_ctrl + Q_AVAIL, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // Claim one published entry.  A failed claim takes Q_AVAIL below its true value until it is restored, which
+        // can make a concurrent claimer fail although an entry has just been published; so whoever fails looks again
+        // after restoring: the last of the failed claimers to restore sees the true count.  (One atomic per claim in
+        // the common case; a compare-and-swap loop here costs O(workers^2) atomics when a launch starts.)
+        int32_t *avail = a->q_ctrl + Q_AVAIL;
+        do {
+            const int old = __hip_atomic_fetch_add(avail, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (old > 0) { ticket = __hip_atomic_fetch_add(a->q_ctrl + Q_HEAD, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            __hip_atomic_fetch_add(avail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } while (__hip_atomic_load(avail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 0);
     }
     ticket = __builtin_amdgcn_readfirstlane(ticket);
     exchanged = ticket >= 0;
@@ -989,15 +1150,33 @@ __device__ __forceinline__ int queue_next(const StepArgs &a, int own, bool hold,
     return __builtin_amdgcn_readfirstlane(next);
 }
 
-// The argument block has ~80 pointers; held in SGPRs across the solver loop they would crowd out the loop's own
-// scalars (the compiler hoists kernel-argument loads to the top of the kernel and then spills them).  Each section
-// of a work item therefore re-reads what it needs from the kernel-argument segment through a pointer the
-// optimiser cannot see through, which ends the live ranges at the section's end.
-typedef const __attribute__((address_space(4))) StepArgs *ArgPtr;
-__device__ __forceinline__ ArgPtr fresh(ArgPtr p)
+// derivatives() at the NS points of one trip, section by section: pH properties of all points, temperature properties
+// of all points, then the rows.  Each section fetches its own fp64 constants (scalar loads from the argument block)
+// and its own share of the reactor constants (LDS), so neither is live outside it, and inside a section the NS
+// evaluations are independent chains for the scheduler to interleave.
+template <bool ROW, int NS>
+__device__ __forceinline__ void rhs_points(const Lane &L, const RKStore &ks, ArgPtr pa, const double (*y)[3], double (*F)[3], bool *bad)
 {
-    asm volatile("" : "+s"(p));
-    return p;
+    PropPH pp[NS]; PropT pt[NS];
+    {
+        ArgPtr a = fresh(pa);
+        const KP c = load_kp(&a->kt);
+        const RK k = fetch_reactor(ks);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) pp[s] = prop_pH(c, k, y[s][SPH]);
+    }
+    {
+        ArgPtr a = fresh(pa);
+        const KT c = load_kt(&a->kt);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) { pt[s] = prop_T(c, y[s][STT]); bad[s] = pt[s].bad; }
+    }
+    {
+        const RK k = fetch_reactor(ks);
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+            rhs_rows<ROW>(L, k, pp[s].H, pp[s].iw, pp[s].bpos, pt[s].kT * pp[s].phi, pt[s].rho, y[s][SCL], y[s][STT], F[s]);
+    }
 }
 
 // One work item: the reactors of wavefront-group `group` advanced by `cnt` outer steps, starting with step `step0`
@@ -1009,7 +1188,7 @@ __device__ __forceinline__ void run_item(ArgPtr pa, const Lane &L, double *lds, 
 {
     using M = LdsMap<LV>;
     ArgPtr a = fresh(pa);                             // ---- section: load the group
-    const int n_zones = a->n, R = a->R;
+    const int n_zones = L.n, R = a->R;
     const int lane = threadIdx.x & 63, seg = lane / n_zones;
     const int64_t q_first = (int64_t)group * R;       // slots of this group; slot q holds reactor perm[q]
     const int64_t q_end = a->q_ctrl ? a->N : a->r1;
@@ -1035,7 +1214,14 @@ __device__ __forceinline__ void run_item(ArgPtr pa, const Lane &L, double *lds, 
     bool frozen = !present, f_valid = false, wrote_k = false, raised = false;
     int steps_done = 0, cost_acc = 0;
     SolverCounters last_cnt = {0, 0, 0, 0, 0};
-    long long diag_trips = 0, diag_newton = 0, diag_fact = 0, diag_jac = 0, diag_f3 = 0;
+    int diag_trips = 0, diag_newton = 0;              // per item: 32 bits are plenty
+#ifdef WT_STAMPS  // block-execution counters cost a ballot and a branch each per trip: diagnostic builds only
+    int diag_fact = 0, diag_jac = 0, diag_f3 = 0;
+#define WT_COUNT(c) ++(c)
+#else
+    constexpr int diag_fact = 0, diag_jac = 0, diag_f3 = 0;
+#define WT_COUNT(c) do { } while (0)
+#endif
 #ifdef WT_STAMPS  // diagnostic build only: shader-clock shares of the loop's sections (never in the product .so)
     long long sec[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long tprev = __builtin_amdgcn_s_memtime();
 #define WT_STAMP(i) do { const long long tn_ = __builtin_amdgcn_s_memtime(); sec[i] += tn_ - tprev; tprev = tn_; } while (0)
@@ -1211,7 +1397,9 @@ __device__ __forceinline__ void run_item(ArgPtr pa, const Lane &L, double *lds, 
                     }
                 }
                 WT_STAMP(1);   // step / attempt prologues
-                if (__ballot(phase == PH_NEWTON && !have_lu) != 0ull) diag_fact++;
+#ifdef WT_STAMPS
+                if (__ballot(phase == PH_NEWTON && !have_lu) != 0ull) WT_COUNT(diag_fact);
+#endif
                 if (phase == PH_NEWTON && !have_lu) {
                     factorize<ROW, LV>(L, J, h, F); have_lu = true; cnt_s.nlu += 2;      // radau.py:454-456
                 }
@@ -1236,30 +1424,30 @@ __device__ __forceinline__ void run_item(ArgPtr pa, const Lane &L, double *lds, 
                     if (newton) p0 = yc[q] + z0;
                     ye[0][q] = p0; ye[1][q] = yc[q] + z1; ye[2][q] = yc[q] + z2;
                 }
-                const RK kr = fetch_reactor(ks);
                 bool b0 = false, b1 = false, b2 = false, b3 = false;
                 if (__ballot(newton) != 0ull) {
-                    // some reactor of the wavefront is in its Newton phase: all three stage points in one
-                    // straight-line block (three independent chains for the scheduler to interleave); the
-                    // other lanes' slot-1/2 results are simply not used
-                    b0 = rhs_full<ROW>(L, kr, ye[0], Fe[0]);
-                    b1 = rhs_full<ROW>(L, kr, ye[1], Fe[1]);
-                    b2 = rhs_full<ROW>(L, kr, ye[2], Fe[2]);
-                    b0 = b0 && eval0; b1 = b1 && newton; b2 = b2 && newton;
+                    // some reactor of the wavefront is in its Newton phase: all three stage points (three independent
+                    // chains for the scheduler to interleave); the other lanes' slot-1/2 results are simply not used
+                    bool bb[3];
+                    rhs_points<ROW, 3>(L, ks, pa, ye, Fe, bb);
+                    b0 = bb[0] && eval0; b1 = bb[1] && newton; b2 = bb[2] && newton;
                     if (eval0 && phase != PH_FNEW) cnt_s.nfev++;
                     if (newton) cnt_s.nfev += 2;
                 } else if (__ballot(eval0) != 0ull) {
-                    b0 = rhs_full<ROW>(L, kr, ye[0], Fe[0]) && eval0;
+                    bool bb[1];
+                    rhs_points<ROW, 1>(L, ks, pa, ye, Fe, bb);
+                    b0 = bb[0] && eval0;
                     if (eval0 && phase != PH_FNEW) cnt_s.nfev++;
                 }
                 if (__ballot(eval3) != 0ull) {
-                    diag_f3++;
-                    double fy[3];
-                    b3 = rhs_full<ROW>(L, kr, yc, fy) && eval3;
+                    WT_COUNT(diag_f3);
+                    double fy[1][3]; bool bb[1];
+                    rhs_points<ROW, 1>(L, ks, pa, &yc, fy, bb);
+                    b3 = bb[0] && eval3;
                     if (eval3) {
                         pend_f = false;       // (counted in nfev when the step was accepted)
 #pragma unroll
-                        for (int q = 0; q < 3; ++q) f[q] = fy[q];
+                        for (int q = 0; q < 3; ++q) f[q] = fy[0][q];
                     }
                 }
                 if (__ballot(b0 || b1 || b2 || b3) != 0ull) {   // rare: a zone temperature outside [0, 100] C
@@ -1394,12 +1582,13 @@ __device__ __forceinline__ void run_item(ArgPtr pa, const Lane &L, double *lds, 
 
                 WT_STAMP(4);   // epilogues (Newton solve, error estimate, accept / reject)
                 // ================= finite-difference Jacobian at (yc, f) when a phase asked for it
-                if (__ballot(need_jac) != 0ull) diag_jac++;
+#ifdef WT_STAMPS
+                if (__ballot(need_jac) != 0ull) WT_COUNT(diag_jac);
+#endif
                 if (need_jac) {
                     bool jbad = false, hf = have_fac; double jval = 0;
                     asm volatile("" ::: "memory");               // a fresh fetch: do not keep the constants live across the epilogue
-                    const RK kj = fetch_reactor(ks);
-                    num_jac<ROW>(L, kj, yc, f, fac, hf, J, jbad, jval); cnt_s.njev++;
+                    num_jac<ROW>(L, ks, [&]() { return &fresh(pa)->kt; }, yc, f, fac, hf, J, jbad, jval); cnt_s.njev++;
                     have_fac = hf;
                     need_jac = false;
                     if (seg_any(L, jbad)) {
@@ -1434,8 +1623,13 @@ __device__ __forceinline__ void run_item(ArgPtr pa, const Lane &L, double *lds, 
                 t_out = t_out + dt;                    // reactor.py:496
                 flow_used = ks.uni[15 * ks.stride];    // reactor.py:497-501
                 // _update_derived_state reactor.py:511-524 (before the clamp)
-                dH = exp10(-y0[SPH]);
-                const PropT pt = prop_T(y0[STT]);
+                double dHv; PropT pt;
+                {
+                    ArgPtr a2 = fresh(pa);
+                    const KP cp = load_kp(&a2->kt); const KT ct = load_kt(&a2->kt);
+                    dHv = exp10_k(cp, -y0[SPH]); pt = prop_T(ct, y0[STT]);
+                }
+                dH = dHv;
                 dR = pt.rho;
                 bool clamped = false;
                 if (seg_any(L, pt.bad)) {
@@ -1552,48 +1746,61 @@ __global__ __launch_bounds__(256) void queue_reset_kernel(const QueueResetArgs a
 // tails: a slow wavefront delays nobody, and with more groups than resident wavefronts every SIMD stays busy.
 // Stream schedule (q_ctrl == nullptr): workgroup b advances group r0 / R + b by n_steps and exits.
 template <int LV, bool ROW>
-__global__ __launch_bounds__(64) void step_kernel(const StepArgs a)
+__global__ __launch_bounds__(64) void step_kernel(const StepArgs a_unused)
 {
+    (void)a_unused;   // never read directly: every section fetches what it needs through `pa` (see fresh())
     __shared__ double lds[LdsMap<LV>::TOTAL];
-    Lane L;
-    lane_geometry(a.n, L);
     // the by-value argument block sits at offset 0 of the kernel-argument segment
     const ArgPtr pa = (ArgPtr)__builtin_amdgcn_kernarg_segment_ptr();
-    const bool queue = a.q_ctrl != nullptr;
+    Lane L;
+    // ROW instantiations serve exactly one zone count (n = 2^LV): a compile-time constant for everything below
+    lane_geometry(ROW ? (1 << LV) : fresh(pa)->n, L);
     bool exchanged = true;
-    int group = queue ? queue_next(a, -1, false, exchanged) : (int)(a.r0 / a.R) + (int)blockIdx.x;
+    int group;
+    {
+        ArgPtr a = fresh(pa);
+        group = a->q_ctrl ? queue_next(pa, -1, false, exchanged) : (int)(a->r0 / a->R) + (int)blockIdx.x;
+    }
     while (group >= 0) {          // (one call site: the item body exists once in the code object)
-        int step0 = 0, cnt = a.n_steps;
+        int step0 = 0, cnt;
         long long t0 = 0;
-        if (queue) {
-            // taken over from another worker: its release (queue_next) -> this acquire -> plain loads of the group's state
-            if (exchanged) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            if ((threadIdx.x & 63) == 0) step0 = __hip_atomic_load(a.q_next + group, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            step0 = __builtin_amdgcn_readfirstlane(step0);
-            const int left = a.n_steps - step0;
-            cnt = left < a.item_steps ? left : a.item_steps;
-            if (a.trace) t0 = __builtin_amdgcn_s_memrealtime();
+        bool queue;
+        {
+            ArgPtr a = fresh(pa);
+            queue = a->q_ctrl != nullptr;
+            cnt = a->n_steps;
+            if (queue) {
+                // taken over from another worker: its release (queue_next) -> this acquire -> plain loads of the group's state
+                if (exchanged) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                if ((threadIdx.x & 63) == 0) step0 = __hip_atomic_load(a->q_next + group, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                step0 = __builtin_amdgcn_readfirstlane(step0);
+                const int left = a->n_steps - step0, item = a->item_steps;
+                cnt = left < item ? left : item;
+                if (a->trace) t0 = __builtin_amdgcn_s_memrealtime();
+            }
         }
         run_item<LV, ROW>(pa, L, lds, group, step0, cnt);
         if (!queue) break;
-        const bool more = step0 + cnt < a.n_steps;
+        ArgPtr a = fresh(pa);
+        const bool more = step0 + cnt < a->n_steps;
         int hold = 0;
         if ((threadIdx.x & 63) == 0) {
-            __hip_atomic_store(a.q_next + group, step0 + cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(a->q_next + group, step0 + cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             // items this group has behind it against the ensemble's average
-            const long long done = __hip_atomic_fetch_add(a.q_ctrl + Q_DONE, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
-            const long long mine = (step0 + cnt + a.item_steps - 1) / a.item_steps;
-            hold = (mine * a.n_groups < done) ? 1 : 0;     // (one item more or less of slack either way: measured worse)
-            if (a.trace) {
-                const int slot = __hip_atomic_fetch_add(a.q_ctrl + Q_TRACE, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (slot < a.trace_cap) {
-                    int64_t *o = a.trace + (int64_t)slot * 5;
+            const long long done = __hip_atomic_fetch_add(a->q_ctrl + Q_DONE, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+            const int item = a->item_steps;
+            const long long mine = (step0 + cnt + item - 1) / item;
+            hold = (mine * a->n_groups < done) ? 1 : 0;     // (one item more or less of slack either way: measured worse)
+            if (a->trace) {
+                const int slot = __hip_atomic_fetch_add(a->q_ctrl + Q_TRACE, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (slot < a->trace_cap) {
+                    int64_t *o = a->trace + (int64_t)slot * 5;
                     o[0] = blockIdx.x; o[1] = group; o[2] = (int64_t)step0 | ((int64_t)cnt << 32); o[3] = t0; o[4] = __builtin_amdgcn_s_memrealtime();
                 }
             }
         }
         hold = __builtin_amdgcn_readfirstlane(hold);
-        group = queue_next(a, more ? group : -1, hold != 0, exchanged);
+        group = queue_next(pa, more ? group : -1, hold != 0, exchanged);
     }
 }
 
@@ -1614,7 +1821,7 @@ __global__ __launch_bounds__(64) void rhs_kernel(const RhsArgs a)
     const int64_t idx = r * a.n + L.z;
     RK k; load_reactor(a.par, a.bc, a.N, r, a.n, k); mask_reactor_for_lane(L, k);
     double y[3] = {a.pH[idx], a.Cl[idx], a.T[idx]}, f[3];
-    const bool bad = rhs_full<ROW>(L, k, y, f);
+    const bool bad = rhs_full<ROW>(L, kp_of(default_ktab()), kt_of(default_ktab()), k, y, f);
     a.dpH[idx] = f[SPH]; a.dCl[idx] = f[SCL]; a.dT[idx] = f[STT];
     const bool anybad = seg_any(L, bad);
     if (L.z == 0) a.flags[r] = anybad ? ST_T_RANGE : 0u;
@@ -1626,7 +1833,7 @@ __global__ __launch_bounds__(256) void derived_placeholder_kernel(const Placehol
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.count) return;
-    a.dH[i] = exp10(-a.pH[i]); a.dRho[i] = 998.2; a.dK[i] = 0.0001;
+    a.dH[i] = exp10_k(kp_of(default_ktab()), -a.pH[i]); a.dRho[i] = 998.2; a.dK[i] = 0.0001;
 }
 
 // Self-test of the cross-lane primitives against ds_bpermute-based __shfl:
@@ -1669,7 +1876,7 @@ __global__ __launch_bounds__(256) void ph_solve_kernel(const PhArgs a)
     int rcode = 2, it = 0;
     for (it = 0; it < a.max_iter; ++it) {
         // charge_balance_error chemistry.py:193-228
-        const double H = exp10(-pH);
+        const double H = exp10_k(kp_of(default_ktab()), -pH);
         const double OH = Kw / H;
         const double H2 = H * H;
         const double D = H2 + Ka1 * H + Ka1 * Ka2;
