@@ -459,24 +459,100 @@ struct PropT { double kT, rho; bool bad; };
 
 // H = 10^-pH, buffering capacity beta (chemistry.py:400-437), HOCl/OCl- decay
 // factor (chemistry.py:483-523).
-__device__ __forceinline__ PropPH prop_pH(const KP &c, const RK &k, double pH)
+
+// ---- the same arithmetic for NS points at once, step by step: consecutive instructions belong to different points and
+// are independent (a dependent fp64 instruction issues after 8 cycles, an independent one after 5: tools/ubench/issue.hip)
+#define WT_EACH _Pragma("unroll") for (int s = 0; s < NS; ++s)
+// The compiler, short of registers, pulls each point's chain together again; an empty asm that "uses and redefines"
+// the step's results makes every step complete for all points before the next one starts (NS = 1: nothing to do).
+template <int NS> __device__ __forceinline__ void row_fence(double (&v)[NS])
+{
+    if constexpr (NS == 2) asm volatile("" : "+v"(v[0]), "+v"(v[1]));
+    if constexpr (NS == 3) asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]));
+    if constexpr (NS == 4) asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));
+}
+template <int NS> __device__ __forceinline__ void rcp_n(const double (&x)[NS], double (&r)[NS])
+{
+    double e[NS];
+    WT_EACH r[s] = __builtin_amdgcn_rcp(x[s]); row_fence(r);
+    WT_EACH e[s] = __builtin_fma(-x[s], r[s], 1.0); row_fence(e);
+    WT_EACH r[s] = __builtin_fma(r[s], e[s], r[s]); row_fence(r);
+    WT_EACH e[s] = __builtin_fma(-x[s], r[s], 1.0); row_fence(e);
+    WT_EACH r[s] = __builtin_fma(r[s], e[s], r[s]); row_fence(r);
+}
+template <int NS> __device__ __forceinline__ void exp_tail_n(const double c[10], const double (&t)[NS], const double (&dn)[NS], double (&z)[NS])
+{
+    double p[NS];
+    WT_EACH p[s] = c[0];
+#pragma unroll
+    for (int i = 1; i < 10; ++i) { WT_EACH p[s] = __builtin_fma(t[s], p[s], c[i]); row_fence(p); }
+    WT_EACH p[s] = __builtin_fma(t[s], p[s], 1.0); row_fence(p);
+    WT_EACH p[s] = __builtin_fma(t[s], p[s], 1.0); row_fence(p);
+    WT_EACH z[s] = __builtin_amdgcn_ldexp(p[s], (int)dn[s]); row_fence(z);
+}
+template <int NS> __device__ __forceinline__ void prop_pH_n(const KP &c, const RK &k, const double (&pH)[NS], PropPH (&p)[NS])
 {
 #pragma clang fp contract(off)
-    PropPH p;
-    const double H = exp10_k(c, -pH);
-    const double beta_w = c.c2303 * __builtin_fma(k.Kw, rcp(H), H);
-    const double H2 = H * H;
-    const double D = __builtin_fma(k.Ka1, H, H2) + k.Ka1Ka2;
-    const double iD = rcp(D);
-    const double a0 = H2 * iD, a1 = (k.Ka1 * H) * iD, a2 = k.Ka1Ka2 * iD;
-    const double mix = __builtin_fma(a0, a2, __builtin_fma(4 * a1, a2, a0 * a1));
-    const double beta = __builtin_fma(k.cbeta, mix, beta_w);
-    p.bpos = beta > 0;                           // reactor.py:358,367,375 guards: no pH change unless beta > 0
-    p.iw = p.bpos ? rcp(beta * c.ln10) : 0.0;
-    const double iHK = rcp(H + k.KaH);
-    p.phi = __builtin_fma(k.KaH * iHK, c.c002, H * iHK);
-    p.H = H;
-    return p;
+    double x[NS], dn[NS], u[NS], t[NS], H[NS];
+    WT_EACH x[s] = -pH[s];
+    WT_EACH dn[s] = __builtin_rint(x[s] * c.log2_10); row_fence(dn);
+    WT_EACH u[s] = __builtin_fma(-dn[s], c.lg2_hi, x[s]); row_fence(u);
+    WT_EACH u[s] = __builtin_fma(-dn[s], c.lg2_lo, u[s]); row_fence(u);
+    WT_EACH t[s] = u[s] * c.ln10_lo; row_fence(t);
+    WT_EACH t[s] = __builtin_fma(u[s], c.ln10_hi, t[s]); row_fence(t);
+    exp_tail_n<NS>(c.c, t, dn, H);
+    WT_EACH H[s] = (x[s] > c.t_hi) ? __builtin_inf() : H[s];
+    WT_EACH H[s] = (x[s] < c.t_lo) ? 0.0 : H[s];
+    double iH[NS], H2[NS], D[NS], iD[NS], HK[NS], iHK[NS];
+    WT_EACH H2[s] = H[s] * H[s];
+    WT_EACH D[s] = __builtin_fma(k.Ka1, H[s], H2[s]) + k.Ka1Ka2;
+    WT_EACH HK[s] = H[s] + k.KaH;
+    rcp_n<NS>(H, iH); rcp_n<NS>(D, iD); rcp_n<NS>(HK, iHK);
+    double bw[NS], a0[NS], a1[NS], a2[NS], mix[NS], beta[NS], bl[NS], ib[NS];
+    WT_EACH bw[s] = c.c2303 * __builtin_fma(k.Kw, iH[s], H[s]);
+    WT_EACH a0[s] = H2[s] * iD[s];
+    WT_EACH a1[s] = (k.Ka1 * H[s]) * iD[s];
+    WT_EACH a2[s] = k.Ka1Ka2 * iD[s];
+    WT_EACH mix[s] = __builtin_fma(a0[s], a2[s], __builtin_fma(4 * a1[s], a2[s], a0[s] * a1[s]));
+    WT_EACH beta[s] = __builtin_fma(k.cbeta, mix[s], bw[s]);
+    WT_EACH bl[s] = beta[s] * c.ln10;
+    rcp_n<NS>(bl, ib);
+    WT_EACH {
+        p[s].bpos = beta[s] > 0;                    // reactor.py:358,367,375 guards: no pH change unless beta > 0
+        p[s].iw = p[s].bpos ? ib[s] : 0.0;
+        p[s].phi = __builtin_fma(k.KaH * iHK[s], c.c002, H[s] * iHK[s]);
+        p[s].H = H[s];
+    }
+}
+template <int NS> __device__ __forceinline__ void prop_T_n(const KT &c, const double (&T)[NS], PropT (&p)[NS])
+{
+#pragma clang fp contract(off)
+    double tk[NS], itk[NS], ex[NS], dn[NS], t[NS], z[NS];
+    WT_EACH tk[s] = T[s] + c.c27315;
+    rcp_n<NS>(tk, itk);
+    WT_EACH ex[s] = c.k_arr * (itk[s] - c.inv_tref);
+    WT_EACH dn[s] = __builtin_rint(ex[s] * c.log2e); row_fence(dn);
+    WT_EACH t[s] = __builtin_fma(-dn[s], c.ln2_hi, ex[s]); row_fence(t);
+    WT_EACH t[s] = __builtin_fma(-dn[s], c.ln2_lo, t[s]); row_fence(t);
+    exp_tail_n<NS>(c.c, t, dn, z);
+    WT_EACH z[s] = (ex[s] > c.e_hi) ? __builtin_inf() : z[s];
+    WT_EACH z[s] = (ex[s] < c.e_lo) ? 0.0 : z[s];
+    WT_EACH {
+        p[s].bad = (T[s] < 0.0) || (T[s] > c.c100);
+        p[s].kT = c.c1em4 * z[s];
+        const double d = T[s] - 4.0;
+        const double cold = c.rho_max + (c.rho_an * (d * d));
+        const double warm = c.rho20 + (c.rho_sl * (T[s] - c.c20));
+        p[s].rho = (T[s] <= c.c8) ? cold : warm;
+    }
+}
+
+// H = 10^-pH, buffering capacity beta (chemistry.py:400-437), HOCl/OCl- decay factor (chemistry.py:483-523).
+__device__ __forceinline__ PropPH prop_pH(const KP &c, const RK &k, double pH)
+{
+    const double x[1] = {pH}; PropPH p[1];
+    prop_pH_n<1>(c, k, x, p);
+    return p[0];
 }
 
 // Arrhenius decay rate (thermodynamics.py:160-193) with its [0,100] C check
@@ -484,59 +560,80 @@ __device__ __forceinline__ PropPH prop_pH(const KP &c, const RK &k, double pH)
 // is formed with the reference's roundings: products and sums separately, never fused.
 __device__ __forceinline__ PropT prop_T(const KT &c, double T)
 {
-#pragma clang fp contract(off)
-    PropT p;
-    p.bad = (T < 0.0) || (T > c.c100);
-    const double ex = c.k_arr * (rcp(T + c.c27315) - c.inv_tref);
-    p.kT = c.c1em4 * exp_k(c, ex);
-    const double d = T - 4.0;
-    const double cold = c.rho_max + (c.rho_an * (d * d));
-    const double warm = c.rho20 + (c.rho_sl * (T - c.c20));
-    p.rho = (T <= c.c8) ? cold : warm;
-    return p;
+    const double x[1] = {T}; PropT p[1];
+    prop_T_n<1>(c, x, p);
+    return p[0];
 }
 
 // One row-triple (dpH, dCl, dT) of derivatives() for this lane's zone, given the
 // lane's own (possibly perturbed / stage) values; neighbour values come from the
 // adjacent lanes' arguments to the same call.  reactor.py:304-443.
 // Cross-lane moves are executed by every lane of the segment, then masked.
-template <bool ROW>
-__device__ __forceinline__ void rhs_rows(const Lane &L, const RK &k, double H, double iw, bool bpos, double kphi,
-                                         double rho, double Cl, double T, double f[3])
+// The pieces of a row, shared by rhs_rows and the finite-difference passes (one rounding behaviour per expression).
+// Interface factor above this zone: K[i,i+1] = Kex * suppression(rho_i, rho_{i+1})  (spatial.py:239-320, reactor.py:321-325).
+// The reference compares the correctly rounded quotient Ri = num / den, num = (g drho) dz, den = rho_avg u^2 > 0, with
+// Ri_crit.  fl(num / den) > c  <=>  num / den > c + ulp(c)/2  <=>  num - c den > (ulp(c)/2) den, and the left side is
+// exact in one fma whenever the two sides are close enough for rounding to matter: the same decision as the
+// reference's on the same bits, without a division.  Stratification off / velocity scale <= 1e-6 (Ri = +inf) are
+// folded into the two outcomes (load_reactor).
+__device__ __forceinline__ double k_above(const RK &k, double rho, double rho_hi)
 {
 #pragma clang fp contract(off)
-    // mixing suppression of the interface above this zone (spatial.py:239-320): the reference compares the
-    // correctly rounded quotient Ri = num / den, num = (g drho) dz, den = rho_avg u^2 > 0, with Ri_crit.
-    // fl(num / den) > c  <=>  num / den > c + ulp(c)/2  <=>  num - c den > (ulp(c)/2) den, and the left side is
-    // exact in one fma whenever the two sides are close enough for rounding to matter: the same decision as the
-    // reference's on the same bits, without a division.
-    // Stratification off / velocity scale <= 1e-6 (Ri = +inf) are folded into the two outcomes (load_reactor).
-    const double rho_hi = from_hi<ROW, 1>(L, rho);
     const double drho = rho_hi - rho;
     const double ravg = 0.5 * (rho + rho_hi);
     const double num = (9.81 * drho) * k.dz, den = ravg * k.u2;
     const double s = (__builtin_fma(-k.ricrit, den, num) > k.rihulp * den) ? k.supp : k.unsupp;
-    const double k_hi = k.Kex_hi * s;                     // K[i,i+1]  reactor.py:321-325 (0 above the top zone)
-    const double k_lo = keep_m(L.m_lo[0], from_lo<ROW, 1>(L, k_hi)); // K[i,i-1] (bound_ctrl gives 0 below zone 0 of lane 0)
-    const double kd = -(k_lo + k_hi) - k.Qv_out;          // reactor.py:329-337
+    return k.Kex_hi * s;                                   // 0 above the top zone
+}
+// K @ x the way OpenBLAS' dgemv accumulates it inside the reference: neighbours first, diagonal last, every product
+// rounded before it is added (pinned by tests/golden/g2_rhs_*.npz: temperature rows bit-identical).
+__device__ __forceinline__ double k_diag(const RK &k, double k_lo, double k_hi)
+{
+#pragma clang fp contract(off)
+    return -(k_lo + k_hi) - k.Qv_out;                      // reactor.py:329-337
+}
+__device__ __forceinline__ double mix3(double k_lo, double k_hi, double kd, double x_lo, double x_hi, double x)
+{
+#pragma clang fp contract(off)
+    return (k_lo * x_lo + k_hi * x_hi) + kd * x;
+}
+// zone-0 dosing and inlet (reactor.py:349-368,388-395,420) through pre-masked coefficients; iw is 0 when the
+// reference's `beta > 0` guard fails
+__device__ __forceinline__ double row_pH(const RK &k, double mixH, double H, double iw)
+{
+#pragma clang fp contract(off)
+    return -(__builtin_fma(k.Qv_in, k.H_in - H, k.acid0) + mixH) * iw;                        // reactor.py:349-376
+}
+__device__ __forceinline__ double row_Cl(const RK &k, double mixC, double Cl, double kphi)
+{
+#pragma clang fp contract(off)
+    return __builtin_fma(-kphi, Cl, __builtin_fma(k.Qv_in, k.Cl_in - Cl, k.dose0) + mixC);    // reactor.py:385-411
+}
+__device__ __forceinline__ double row_T(const RK &k, double mixT, double T)
+{
+#pragma clang fp contract(off)
+    return __builtin_fma(-k.UAr_on, T - k.T_amb, k.Qv_in * (k.T_in - T) + mixT);               // reactor.py:420-443
+}
 
+// One row-triple (dpH, dCl, dT) of derivatives() for this lane's zone, given the
+// lane's own (possibly stage) values; neighbour values come from the
+// adjacent lanes' arguments to the same call.  reactor.py:304-443.
+// Cross-lane moves are executed by every lane of the segment, then masked.
+template <bool ROW>
+__device__ __forceinline__ void rhs_rows(const Lane &L, const RK &k, double H, double iw, bool bpos, double kphi,
+                                         double rho, double Cl, double T, double f[3])
+{
+    const double k_hi = k_above(k, rho, from_hi<ROW, 1>(L, rho));       // K[i,i+1]
+    const double k_lo = keep_m(L.m_lo[0], from_lo<ROW, 1>(L, k_hi));    // K[i,i-1] (bound_ctrl gives 0 below zone 0 of lane 0)
+    const double kd = k_diag(k, k_lo, k_hi);
     const double H_lo = keep_m(L.m_lo[0], from_lo<ROW, 1>(L, H)), H_hi = keep_m(L.m_hi[0], from_hi<ROW, 1>(L, H));
     const double C_lo = keep_m(L.m_lo[0], from_lo<ROW, 1>(L, Cl)), C_hi = keep_m(L.m_hi[0], from_hi<ROW, 1>(L, Cl));
     const double T_lo = keep_m(L.m_lo[0], from_lo<ROW, 1>(L, T)), T_hi = keep_m(L.m_hi[0], from_hi<ROW, 1>(L, T));
-    // K @ x the way OpenBLAS' dgemv accumulates it inside the reference: neighbours first, diagonal last, every
-    // product rounded before it is added (pinned by tests/golden/g2_rhs_*.npz: temperature rows bit-identical).
-    // k_lo / k_hi are exactly 0 where there is no neighbour, and what was read there is finite (keep_m).
-    const double mixH = (k_lo * H_lo + k_hi * H_hi) + kd * H;
-    const double mixC = (k_lo * C_lo + k_hi * C_hi) + kd * Cl;
-    const double mixT = (k_lo * T_lo + k_hi * T_hi) + kd * T;
-
-    // zone-0 dosing and inlet (reactor.py:349-368,388-395,420) through pre-masked coefficients;
-    // iw is 0 when the reference's `beta > 0` guard fails
-    const double dpH = -(__builtin_fma(k.Qv_in, k.H_in - H, k.acid0) + mixH) * iw;          // reactor.py:349-376
-    const double dCl = __builtin_fma(-kphi, Cl, __builtin_fma(k.Qv_in, k.Cl_in - Cl, k.dose0) + mixC);   // reactor.py:385-411
-    const double dT = __builtin_fma(-k.UAr_on, T - k.T_amb, k.Qv_in * (k.T_in - T) + mixT);  // reactor.py:420-443
+    // k_lo / k_hi are exactly 0 where there is no neighbour, and what was read there is finite (keep_m)
     (void)bpos;
-    f[SPH] = dpH; f[SCL] = dCl; f[STT] = dT;
+    f[SPH] = row_pH(k, mix3(k_lo, k_hi, kd, H_lo, H_hi, H), H, iw);
+    f[SCL] = row_Cl(k, mix3(k_lo, k_hi, kd, C_lo, C_hi, Cl), Cl, kphi);
+    f[STT] = row_T(k, mix3(k_lo, k_hi, kd, T_lo, T_hi, T), T);
 }
 
 template <bool ROW>
@@ -803,58 +900,86 @@ struct FdCols { double D[3][3]; double S[3][3]; }; // [row species][rel+1]: diff
 
 struct ZoneProps { double H, iw, phi, kT, rho; bool bpos; };
 
-// pick x[idx], idx in {0,1,2}, without a runtime-indexed array (those go to scratch memory)
-__device__ __forceinline__ double sel3(double x0, double x1, double x2, int idx)
+// What the rows of this lane see of their neighbourhood at the unperturbed state (once per Jacobian)
+struct FdBase { double k_lo, k_hi, kd, H_lo, H_hi, C_lo, C_hi, T_lo, T_hi, rho_hi; };
+
+template <bool ROW>
+__device__ __forceinline__ FdBase fd_base(const Lane &L, const RK &k, const double y[3], const ZoneProps &b)
 {
-    return (idx == 0) ? x0 : ((idx == 1) ? x1 : x2);
+    FdBase n;
+    n.rho_hi = from_hi<ROW, 1>(L, b.rho);
+    n.k_hi = k_above(k, b.rho, n.rho_hi);
+    n.k_lo = keep_m(L.m_lo[0], from_lo<ROW, 1>(L, n.k_hi));
+    n.kd = k_diag(k, n.k_lo, n.k_hi);
+    n.H_lo = keep_m(L.m_lo[0], from_lo<ROW, 1>(L, b.H)); n.H_hi = keep_m(L.m_hi[0], from_hi<ROW, 1>(L, b.H));
+    n.C_lo = keep_m(L.m_lo[0], from_lo<ROW, 1>(L, y[SCL])); n.C_hi = keep_m(L.m_hi[0], from_hi<ROW, 1>(L, y[SCL]));
+    n.T_lo = keep_m(L.m_lo[0], from_lo<ROW, 1>(L, y[STT])); n.T_hi = keep_m(L.m_hi[0], from_hi<ROW, 1>(L, y[STT]));
+    return n;
 }
 
-// Three colour passes of one species.  Results come back indexed by neighbour offset:
+// The columns of one species: every zone's own value perturbed by its own step.  A row of zone i changes with the
+// columns of zones i-1, i, i+1 only, and which of its inputs a column reaches is known: so each row is evaluated
+// three times -- with its own zone's perturbed values, with what its lower neighbour exports when perturbed, with what
+// its upper neighbour exports -- everything else at the base values.  This is f(y + h e_j) - f(y) of common.py:331-333
+// restricted to the rows that can change; rows that cannot depend on a column are structural zeros there too.
 // out.D[q][r] is the change of this lane's row q when the zone at offset r-1 was perturbed.
+// colmask (retry pass, common.py:343-361): only the flagged columns are perturbed.
 template <bool ROW, int SP, class KC>
 __device__ __forceinline__ void fd_species_pass(const Lane &L, const KC &kc, const RK &k, const double y[3], const double f[3],
-                                                const ZoneProps &b, double hcol, bool colmask, FdCols &out, bool &bad, double &badval)
+                                                const ZoneProps &b, const FdBase &n, double hcol, bool colmask, bool all_cols,
+                                                FdCols &out, bool &bad, double &badval)
 {
     const double ypert = y[SP] + hcol;
-    ZoneProps p = b;
-    if constexpr (SP == SPH) { const PropPH q = prop_pH(kc, k, ypert); p.H = q.H; p.iw = q.iw; p.phi = q.phi; p.bpos = q.bpos; }
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int r = 0; r < 3; ++r) { out.D[q][r] = 0.0; out.S[q][r] = 0.0; }
+    auto put = [&](int q, int r, double fn) { out.D[q][r] = fn - f[q]; out.S[q][r] = fmax(fabs(f[q]), fabs(fn)); };
+    const double kphi = b.kT * b.phi;
+    if constexpr (SP == SPH) {
+        PropPH p = prop_pH(kc, k, ypert);
+        if (!all_cols && !colmask) { p.H = b.H; p.iw = b.iw; p.phi = b.phi; }        // this column is not part of the retry
+        const double Hx_lo = keep_m(L.m_lo[0], from_lo<ROW, 1>(L, p.H)), Hx_hi = keep_m(L.m_hi[0], from_hi<ROW, 1>(L, p.H));
+        put(SPH, 1, row_pH(k, mix3(n.k_lo, n.k_hi, n.kd, n.H_lo, n.H_hi, p.H), p.H, p.iw));
+        put(SCL, 1, row_Cl(k, mix3(n.k_lo, n.k_hi, n.kd, n.C_lo, n.C_hi, y[SCL]), y[SCL], b.kT * p.phi));
+        put(SPH, 0, row_pH(k, mix3(n.k_lo, n.k_hi, n.kd, Hx_lo, n.H_hi, b.H), b.H, b.iw));
+        put(SPH, 2, row_pH(k, mix3(n.k_lo, n.k_hi, n.kd, n.H_lo, Hx_hi, b.H), b.H, b.iw));
+    }
+    if constexpr (SP == SCL) {
+        const double cx = (all_cols || colmask) ? ypert : y[SCL];
+        const double Cx_lo = keep_m(L.m_lo[0], from_lo<ROW, 1>(L, cx)), Cx_hi = keep_m(L.m_hi[0], from_hi<ROW, 1>(L, cx));
+        put(SCL, 1, row_Cl(k, mix3(n.k_lo, n.k_hi, n.kd, n.C_lo, n.C_hi, cx), cx, kphi));
+        put(SCL, 0, row_Cl(k, mix3(n.k_lo, n.k_hi, n.kd, Cx_lo, n.C_hi, y[SCL]), y[SCL], kphi));
+        put(SCL, 2, row_Cl(k, mix3(n.k_lo, n.k_hi, n.kd, n.C_lo, Cx_hi, y[SCL]), y[SCL], kphi));
+    }
     if constexpr (SP == STT) {
-        const PropT q = prop_T(kc, ypert); p.kT = q.kT; p.rho = q.rho;
-        if (colmask && q.bad && !bad) { bad = true; badval = ypert; }   // the reference raises on this perturbed column
-    }
-    const int zm = L.z % 3;
-    double Dc[3][3], Sc[3][3];   // [row species][colour], statically indexed
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        const bool mine = (zm == c) && colmask;
-        const double H = mine ? p.H : b.H, iw = mine ? p.iw : b.iw, rho = mine ? p.rho : b.rho;
-        const bool bpos = mine ? p.bpos : b.bpos;
-        const double kphi = mine ? p.kT * p.phi : b.kT * b.phi;
-        const double cl = (SP == SCL && mine) ? ypert : y[SCL];
-        const double tt = (SP == STT && mine) ? ypert : y[STT];
-        double fn[3];
-        rhs_rows<ROW>(L, k, H, iw, bpos, kphi, rho, cl, tt, fn);
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            Dc[q][c] = fn[q] - f[q];
-            Sc[q][c] = fmax(fabs(f[q]), fabs(fn[q]));
+        PropT p = prop_T(kc, ypert);
+        if (colmask && p.bad && !bad) { bad = true; badval = ypert; }   // the reference raises on this perturbed column
+        double tx = ypert;
+        if (!all_cols && !colmask) { p.kT = b.kT; p.rho = b.rho; tx = y[STT]; }
+        const double Tx_lo = keep_m(L.m_lo[0], from_lo<ROW, 1>(L, tx)), Tx_hi = keep_m(L.m_hi[0], from_hi<ROW, 1>(L, tx));
+        // the two interfaces of a zone move with its density: K[i,i+1] with this zone / with the zone above perturbed
+        const double khi_own = k_above(k, p.rho, n.rho_hi);
+        const double khi_up = k_above(k, b.rho, from_hi<ROW, 1>(L, p.rho));
+        const double klo_own = keep_m(L.m_lo[0], from_lo<ROW, 1>(L, khi_up));    // K[i,i-1] with this zone perturbed
+        const double klo_dn = keep_m(L.m_lo[0], from_lo<ROW, 1>(L, khi_own));    // ... with the zone below perturbed
+        {   // own zone
+            const double kd = k_diag(k, klo_own, khi_own);
+            put(SPH, 1, row_pH(k, mix3(klo_own, khi_own, kd, n.H_lo, n.H_hi, b.H), b.H, b.iw));
+            put(SCL, 1, row_Cl(k, mix3(klo_own, khi_own, kd, n.C_lo, n.C_hi, y[SCL]), y[SCL], p.kT * b.phi));
+            put(STT, 1, row_T(k, mix3(klo_own, khi_own, kd, n.T_lo, n.T_hi, tx), tx));
         }
-    }
-    // the zone at offset r-1 has colour (zm + r + 2) mod 3
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-        const int c = (zm + r + 2) % 3;
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            // rows that cannot depend on a column of species SP are structural zeros
-            const bool dep = (r == 1) ? ((q == SP) || (SP == STT) || (q == SCL && SP == SPH))
-                                      : ((q == SP) || (SP == STT));
-            if (dep) {
-                out.D[q][r] = sel3(Dc[q][0], Dc[q][1], Dc[q][2], c);
-                out.S[q][r] = sel3(Sc[q][0], Sc[q][1], Sc[q][2], c);
-            } else {
-                out.D[q][r] = 0.0; out.S[q][r] = 0.0;
-            }
+        {   // zone below
+            const double kd = k_diag(k, klo_dn, n.k_hi);
+            put(SPH, 0, row_pH(k, mix3(klo_dn, n.k_hi, kd, n.H_lo, n.H_hi, b.H), b.H, b.iw));
+            put(SCL, 0, row_Cl(k, mix3(klo_dn, n.k_hi, kd, n.C_lo, n.C_hi, y[SCL]), y[SCL], kphi));
+            put(STT, 0, row_T(k, mix3(klo_dn, n.k_hi, kd, Tx_lo, n.T_hi, y[STT]), y[STT]));
+        }
+        {   // zone above
+            const double kd = k_diag(k, n.k_lo, khi_up);
+            put(SPH, 2, row_pH(k, mix3(n.k_lo, khi_up, kd, n.H_lo, n.H_hi, b.H), b.H, b.iw));
+            put(SCL, 2, row_Cl(k, mix3(n.k_lo, khi_up, kd, n.C_lo, n.C_hi, y[SCL]), y[SCL], kphi));
+            put(STT, 2, row_T(k, mix3(n.k_lo, khi_up, kd, n.T_lo, Tx_hi, y[STT]), y[STT]));
         }
     }
 }
@@ -894,13 +1019,13 @@ __device__ __forceinline__ double fd_step(double y, double fac, double ysc)
 // (already divided by the column's h).
 template <bool ROW, int SP, class KC>
 __device__ __forceinline__ void num_jac_species(const Lane &L, const KC &kc, const RK &k, const double y[3], const double f[3],
-                                                const ZoneProps &b, double &fac, FdCols &cols, bool &bad, double &badval)
+                                                const ZoneProps &b, const FdBase &nb, double &fac, FdCols &cols, bool &bad, double &badval)
 {
     const double fs = (f[SP] >= 0) ? 1.0 : -1.0;
     const double ysc = fs * fmax(ATOL, fabs(y[SP]));
     double h = fd_step(y[SP], fac, ysc);
     while (h == 0) { fac *= 10; h = fd_step(y[SP], fac, ysc); }    // common.py:327-330
-    fd_species_pass<ROW, SP>(L, kc, k, y, f, b, h, true, cols, bad, badval);
+    fd_species_pass<ROW, SP>(L, kc, k, y, f, b, nb, h, true, true, cols, bad, badval);
     double maxd, scl;
     fd_col_reduce<ROW, SP>(L, cols, maxd, scl);
     const bool small = maxd < rc::NJ_REJECT * scl;                  // common.py:341
@@ -908,7 +1033,7 @@ __device__ __forceinline__ void num_jac_species(const Lane &L, const KC &kc, con
         const double nf = 10 * fac;
         const double hn = fd_step(y[SP], nf, ysc);
         FdCols c2;
-        fd_species_pass<ROW, SP>(L, kc, k, y, f, b, hn, small, c2, bad, badval);
+        fd_species_pass<ROW, SP>(L, kc, k, y, f, b, nb, hn, small, false, c2, bad, badval);
         double md2, sc2;
         fd_col_reduce<ROW, SP>(L, c2, md2, sc2);
         const bool upd = small && (maxd * sc2 < md2 * scl);         // common.py:354
@@ -944,6 +1069,7 @@ __device__ __forceinline__ void num_jac(const Lane &L, const RKStore &ks, KTP kt
     if (!have_fac) { fac[0] = fac[1] = fac[2] = rc::NJ_F0; have_fac = true; }
     FdCols cols;
     ZoneProps b;
+    FdBase nb;
     {
         const KT ct = load_kt(ktab());
         const PropT bpt = prop_T(ct, y[STT]);
@@ -954,21 +1080,22 @@ __device__ __forceinline__ void num_jac(const Lane &L, const RKStore &ks, KTP kt
         const RK k = fetch_reactor(ks);
         const PropPH bpp = prop_pH(cp, k, y[SPH]);
         b.H = bpp.H; b.iw = bpp.iw; b.phi = bpp.phi; b.bpos = bpp.bpos;
-        num_jac_species<ROW, SPH>(L, cp, k, y, f, b, fac[SPH], cols, bad, badval);
+        nb = fd_base<ROW>(L, k, y, b);
+        num_jac_species<ROW, SPH>(L, cp, k, y, f, b, nb, fac[SPH], cols, bad, badval);
 #pragma unroll
         for (int r = 0; r < 3; ++r) J.pp[r] = cols.D[SPH][r];
         J.cp = cols.D[SCL][1];
     }
     {
         const RK k = fetch_reactor(ks);
-        num_jac_species<ROW, SCL>(L, 0, k, y, f, b, fac[SCL], cols, bad, badval);
+        num_jac_species<ROW, SCL>(L, 0, k, y, f, b, nb, fac[SCL], cols, bad, badval);
 #pragma unroll
         for (int r = 0; r < 3; ++r) J.cc[r] = cols.D[SCL][r];
     }
     {
         const KT ct = load_kt(ktab());
         const RK k = fetch_reactor(ks);
-        num_jac_species<ROW, STT>(L, ct, k, y, f, b, fac[STT], cols, bad, badval);
+        num_jac_species<ROW, STT>(L, ct, k, y, f, b, nb, fac[STT], cols, bad, badval);
 #pragma unroll
         for (int r = 0; r < 3; ++r) { J.tt[r] = cols.D[STT][r]; J.pt[r] = cols.D[SPH][r]; J.ct[r] = cols.D[SCL][r]; }
     }
@@ -1162,14 +1289,20 @@ __device__ __forceinline__ void rhs_points(const Lane &L, const RKStore &ks, Arg
         ArgPtr a = fresh(pa);
         const KP c = load_kp(&a->kt);
         const RK k = fetch_reactor(ks);
+        double x[NS];
 #pragma unroll
-        for (int s = 0; s < NS; ++s) pp[s] = prop_pH(c, k, y[s][SPH]);
+        for (int s = 0; s < NS; ++s) x[s] = y[s][SPH];
+        prop_pH_n<NS>(c, k, x, pp);
     }
     {
         ArgPtr a = fresh(pa);
         const KT c = load_kt(&a->kt);
+        double x[NS];
 #pragma unroll
-        for (int s = 0; s < NS; ++s) { pt[s] = prop_T(c, y[s][STT]); bad[s] = pt[s].bad; }
+        for (int s = 0; s < NS; ++s) x[s] = y[s][STT];
+        prop_T_n<NS>(c, x, pt);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) bad[s] = pt[s].bad;
     }
     {
         const RK k = fetch_reactor(ks);
