@@ -45,6 +45,10 @@ constexpr int WT_DIAG_SLOTS = 8;
 #endif
 
 constexpr int SPH = 0, SCL = 1, STT = 2;  // species index inside a lane
+// Branch weights matter beyond the branch: the register allocator keeps in VGPRs what the frequent blocks use
+// and parks the rest in AGPRs, so the rare paths of the solver loop are marked as such.
+#define WT_RARE(x) __builtin_expect(!!(x), 0)
+#define WT_USUAL(x) __builtin_expect(!!(x), 1)
 constexpr double RTOL = 1e-6, ATOL = 1e-8; // reactor.py:481-483
 constexpr int NEWTON_MAXITER = 6;          // radau.py:43
 constexpr double MIN_FACTOR = 0.2, MAX_FACTOR = 10.0;
@@ -239,6 +243,7 @@ struct StepArgs {
 enum { Q_AVAIL = 0, Q_HEAD = 1, Q_TAIL = 2, Q_ERROR = 3, Q_TRACE = 4, Q_DONE = 5, Q_WORDS = 16 };
 
 // ---------------------------------------------------------------- lane geometry and cross-lane moves
+struct Divisor { double d, inv; };     // a fixed divisor and RN(1 / d): div_by()
 struct Lane {
     int n, z;
     bool has_lo, has_hi;
@@ -249,6 +254,7 @@ struct Lane {
     int a_lo[7], a_hi[7];     // ds_bpermute byte addresses of lane -/+ 2^l (segments that straddle DPP rows)
     int base;                 // lane id of zone 0 of this segment
     unsigned long long segmask;
+    Divisor d3n, d9n;         // 3n, 9n: component counts of the RMS norms (common.py:63-65, radau.py:105)
 };
 
 template <int CTRL> __device__ __forceinline__ double dpp_mov(double x)
@@ -329,7 +335,30 @@ __device__ __forceinline__ double rcp(double x)
 
 // x^(1/4) and x^(-1/4) for the step-size controller (radau.py:171-174, common.py:130)
 // through two square roots instead of the general pow(); the result only steers h.
-__device__ __forceinline__ double root4(double x) { return sqrt(sqrt(x)); }
+// sqrt: the library's iteration (reciprocal square root seed, two Goldschmidt steps, one correction: correctly rounded)
+// without its rescaling of arguments below 2^-767, which the norms and step-size ratios formed here never are
+// (0, +inf and NaN behave as in the library).  Half the instructions.
+__device__ __forceinline__ double sqrt_k(double x)
+{
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = y * 0.5;
+    const double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g); h = __builtin_fma(h, r, h);
+    double d = __builtin_fma(-g, g, x); g = __builtin_fma(d, h, g);
+    d = __builtin_fma(-g, g, x); g = __builtin_fma(d, h, g);
+    return __builtin_amdgcn_class(x, 0x260) ? x : g;       // +-0, +inf
+}
+__device__ __forceinline__ double root4(double x) { return sqrt_k(sqrt_k(x)); }
+
+// x / d for a fixed divisor, correctly rounded like the division it replaces (Markstein: q = x * RN(1/d) is within
+// an ulp, its residual is exact in one fma, one more fma rounds correctly): three instructions instead of fourteen.
+__device__ __forceinline__ double div_by(double x, const Divisor &c)
+{
+    const double q = x * c.inv;
+    const double r = __builtin_fma(-c.d, q, x);
+    const double q2 = __builtin_fma(r, c.inv, q);
+    return __builtin_amdgcn_class(q, 0x204) ? q : q2;      // +-inf stays inf (its residual is NaN)
+}
 
 // rate ** k for k = 1..6 (radau.py:113) by repeated multiplication
 __device__ __forceinline__ double powi6(double x, int k)
@@ -703,7 +732,6 @@ __device__ __forceinline__ void pcr_factor_level_all(const Lane &L, double ar[3]
 {
     using S = FSlots<LV>;
     constexpr int s = 1 << l;
-    const bool vlo = L.z - s >= 0, vhi = L.z + s < L.n;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         // real shift.  Every lane inverts its own diagonal once and the neighbours fetch the reciprocal (the same
@@ -713,9 +741,9 @@ __device__ __forceinline__ void pcr_factor_level_all(const Lane &L, double ar[3]
         const double a_lo = from_lo<ROW, s>(L, ar[k]), c_lo = from_lo<ROW, s>(L, cr[k]);
         const double a_hi = from_hi<ROW, s>(L, ar[k]), c_hi = from_hi<ROW, s>(L, cr[k]);
         // a == 0 where there is no lower neighbour (c likewise), so alpha/gamma vanish there by
-        // themselves once the foreign operands are finite
-        const double al = ar[k] * (vlo ? id_lo : 1.0);
-        const double ga = cr[k] * (vhi ? id_hi : 1.0);
+        // themselves once the foreign operands are finite (keep_m folds into the cross-lane move)
+        const double al = ar[k] * keep_m(L.m_lo[l], id_lo);
+        const double ga = cr[k] * keep_m(L.m_hi[l], id_hi);
         dr[k] = dr[k] - al * keep_m(L.m_lo[l], c_lo) - ga * keep_m(L.m_hi[l], a_hi);
         ar[k] = -al * keep_m(L.m_lo[l], a_lo);
         cr[k] = -ga * keep_m(L.m_hi[l], c_hi);
@@ -728,8 +756,8 @@ __device__ __forceinline__ void pcr_factor_level_all(const Lane &L, double ar[3]
         const cplx i_lo = cfrom_lo<ROW, s>(L, cid), i_hi = cfrom_hi<ROW, s>(L, cid);
         const cplx a_lo = cfrom_lo<ROW, s>(L, ac[k]), c_lo = cfrom_lo<ROW, s>(L, cc[k]);
         const cplx a_hi = cfrom_hi<ROW, s>(L, ac[k]), c_hi = cfrom_hi<ROW, s>(L, cc[k]);
-        const cplx il = {vlo ? i_lo.r : 1.0, keep_m(L.m_lo[l], i_lo.i)};
-        const cplx ih = {vhi ? i_hi.r : 1.0, keep_m(L.m_hi[l], i_hi.i)};
+        const cplx il = {keep_m(L.m_lo[l], i_lo.r), keep_m(L.m_lo[l], i_lo.i)};
+        const cplx ih = {keep_m(L.m_hi[l], i_hi.r), keep_m(L.m_hi[l], i_hi.i)};
         const cplx al = cmul(ac[k], il);
         const cplx ga = cmul(cc[k], ih);
         {   // d -= al * c_lo + ga * a_hi, eight fused multiply-adds
@@ -1024,12 +1052,12 @@ __device__ __forceinline__ void num_jac_species(const Lane &L, const KC &kc, con
     const double fs = (f[SP] >= 0) ? 1.0 : -1.0;
     const double ysc = fs * fmax(ATOL, fabs(y[SP]));
     double h = fd_step(y[SP], fac, ysc);
-    while (h == 0) { fac *= 10; h = fd_step(y[SP], fac, ysc); }    // common.py:327-330
+    while (WT_RARE(h == 0)) { fac *= 10; h = fd_step(y[SP], fac, ysc); }    // common.py:327-330
     fd_species_pass<ROW, SP>(L, kc, k, y, f, b, nb, h, true, true, cols, bad, badval);
     double maxd, scl;
     fd_col_reduce<ROW, SP>(L, cols, maxd, scl);
     const bool small = maxd < rc::NJ_REJECT * scl;                  // common.py:341
-    if (__ballot(small) != 0ull) {                                  // rare: one retry with 10x factor
+    if (WT_RARE(__ballot(small) != 0ull)) {                         // rare: one retry with 10x factor
         const double nf = 10 * fac;
         const double hn = fd_step(y[SP], nf, ysc);
         FdCols c2;
@@ -1109,7 +1137,7 @@ __device__ __forceinline__ double rms3(const Lane &L, const double x[3], const d
     double s = 0.0;
 #pragma unroll
     for (int q = 0; q < 3; ++q) { const double v = x[q] * rcp(sc[q]); s += v * v; }
-    return sqrt(seg_sum<ROW>(L, s) / (double)(3 * L.n));
+    return sqrt_k(div_by(seg_sum<ROW>(L, s), L.d3n));
 }
 
 __device__ __forceinline__ double ulp_above(double t)
@@ -1172,6 +1200,8 @@ __device__ __forceinline__ void lane_geometry(int n, Lane &L)
         asm("" : "+v"(L.m_hi[l]));
     }
     L.segmask = ((n >= 64) ? ~0ull : ((1ull << n) - 1ull)) << L.base;
+    L.d3n = {(double)(3 * n), 1.0 / (double)(3 * n)};
+    L.d9n = {(double)(9 * n), 1.0 / (double)(9 * n)};
 }
 
 // rhs_kernel / selftest: one wavefront-group per workgroup
@@ -1378,7 +1408,7 @@ __device__ __forceinline__ void run_item(ArgPtr pa, const Lane &L, double *lds, 
         bool stepped = false;
         if (!frozen) {
           // scipy refuses a non-finite initial state: ValueError out of step(), self.state untouched (base.py:19-20)
-          if (seg_any(L, !(isfinite(y0[0]) && isfinite(y0[1]) && isfinite(y0[2])))) { st |= ST_NONFINITE; frozen = true; }
+          if (WT_RARE(seg_any(L, !(isfinite(y0[0]) && isfinite(y0[1]) && isfinite(y0[2]))))) { st |= ST_NONFINITE; frozen = true; }
           else {
             // ================= one IntegratedCSTR.step(): a fresh scipy solver object (reactor.py:476)
             double yc[3], W[3][3];                    // solver's current y; Newton iterate in transformed variables
@@ -1487,8 +1517,8 @@ __device__ __forceinline__ void run_item(ArgPtr pa, const Lane &L, double *lds, 
                 }
                 if (phase == PH_ATTEMPT) {
                     if (!keep_h) {
-                        if (step_limit > 0 && attempts >= step_limit) { failed = true; limit_hit = true; phase = PH_DONE; }
-                        else if (h_abs_l < min_step) { failed = true; phase = PH_DONE; }  // radau.py:427-428
+                        if (WT_RARE(step_limit > 0 && attempts >= step_limit)) { failed = true; limit_hit = true; phase = PH_DONE; }
+                        else if (WT_RARE(h_abs_l < min_step)) { failed = true; phase = PH_DONE; }  // radau.py:427-428
                         else {
                             attempts++;
                             h = h_abs_l;
@@ -1583,7 +1613,7 @@ __device__ __forceinline__ void run_item(ArgPtr pa, const Lane &L, double *lds, 
                         for (int q = 0; q < 3; ++q) f[q] = fy[0][q];
                     }
                 }
-                if (__ballot(b0 || b1 || b2 || b3) != 0ull) {   // rare: a zone temperature outside [0, 100] C
+                if (WT_RARE(__ballot(b0 || b1 || b2 || b3) != 0ull)) {   // rare: a zone temperature outside [0, 100] C
                     // the reference raises in the first evaluation, at the first zone, that sees it: scipy calls
                     // f(y_new) of the accepted step before the stages of the next Newton iteration
                     const bool mine = b0 || b1 || b2 || b3;
@@ -1597,7 +1627,7 @@ __device__ __forceinline__ void run_item(ArgPtr pa, const Lane &L, double *lds, 
 
                 WT_STAMP(3);   // RHS evaluations
                 // ================= per-phase epilogues
-                if (phase == PH_OUTER_BEGIN) {
+                if (WT_RARE(phase == PH_OUTER_BEGIN)) {   // (rare: f(y0) is usually carried over from the previous outer step)
 #pragma unroll
                     for (int q = 0; q < 3; ++q) f[q] = Fe[0][q];
                     phase = PH_INIT_STEP;
@@ -1620,7 +1650,7 @@ __device__ __forceinline__ void run_item(ArgPtr pa, const Lane &L, double *lds, 
 #pragma unroll
                         for (int q = 0; q < 3; ++q) finite = finite && isfinite(Fe[s][q]);
                     bool conv = false, diverged = false;
-                    if (!seg_all(L, finite)) {
+                    if (WT_RARE(!seg_all(L, finite))) {
                         diverged = true;
                     } else {
                         const double ih = rcp(h);
@@ -1643,7 +1673,7 @@ __device__ __forceinline__ void run_item(ArgPtr pa, const Lane &L, double *lds, 
                             const double u = fr[q] * is, v = fcr[q] * is, w = fci[q] * is;
                             ssum += u * u + v * v + w * w;
                         }
-                        const double dW_norm = sqrt(seg_sum<ROW>(L, ssum) / (double)(9 * L.n));
+                        const double dW_norm = sqrt_k(div_by(seg_sum<ROW>(L, ssum), L.d9n));
                         if (have_norm_old) { rate = dW_norm * rcp(dW_norm_old); have_rate = true; }
                         const double i1r = rcp(1 - rate);
                         if (have_rate && (rate >= 1 || powi6(rate, NEWTON_MAXITER - kk) * i1r * dW_norm > rc::NEWTON_TOL)) {
@@ -1658,7 +1688,7 @@ __device__ __forceinline__ void run_item(ArgPtr pa, const Lane &L, double *lds, 
                     n_iter = kk + 1;
                     kk++;
                     if (!conv && !diverged && kk == NEWTON_MAXITER) diverged = true;   // loop ran out: radau.py:136
-                    if (diverged) {                                                   // radau.py:462-476
+                    if (WT_RARE(diverged)) {                                          // radau.py:462-476
                         if (current_jac) { h_abs_l *= 0.5; have_lu = false; cnt_s.nrej++; phase = PH_ATTEMPT; }
                         else { need_jac = true; current_jac = true; have_lu = false; keep_h = true; phase = PH_ATTEMPT; }
                     } else if (conv) {
@@ -1677,17 +1707,17 @@ __device__ __forceinline__ void run_item(ArgPtr pa, const Lane &L, double *lds, 
                         solve_real<ROW, LV>(L, J, F, err);
                         error_norm = rms3<ROW>(L, err, esc);
                         safety = 0.9 * (2 * NEWTON_MAXITER + 1) / (2 * NEWTON_MAXITER + n_iter);
-                        if (rejected && error_norm > 1) {
+                        if (WT_RARE(rejected && error_norm > 1)) {
 #pragma unroll
                             for (int q = 0; q < 3; ++q) aux[q] = err[q];
                             phase = PH_ERR_REFINE;
-                        } else if (error_norm > 1) {                                  // radau.py:489-496
+                        } else if (WT_RARE(error_norm > 1)) {                         // radau.py:489-496
                             reject_step();
                         } else {
                             accept_step();
                         }
                     }
-                } else if (phase == PH_ERR_REFINE) {
+                } else if (WT_RARE(phase == PH_ERR_REFINE)) {
                     double err[3], esc[3];
                     const double ih_e = rcp(h);
 #pragma unroll
@@ -1724,7 +1754,7 @@ __device__ __forceinline__ void run_item(ArgPtr pa, const Lane &L, double *lds, 
                     num_jac<ROW>(L, ks, [&]() { return &fresh(pa)->kt; }, yc, f, fac, hf, J, jbad, jval); cnt_s.njev++;
                     have_fac = hf;
                     need_jac = false;
-                    if (seg_any(L, jbad)) {
+                    if (WT_RARE(seg_any(L, jbad))) {
                         if (jbad && !bad) { badstage = 4; badval = jval; }
                         bad |= jbad; raised = true; phase = PH_DONE;
                     }
@@ -1735,7 +1765,7 @@ __device__ __forceinline__ void run_item(ArgPtr pa, const Lane &L, double *lds, 
             cost_acc += cnt_s.nfev;
 
             // ================= after the solve: reactor.py:486-507
-            if (raised) {
+            if (WT_RARE(raised)) {
                 // the reference raised (thermodynamics.py:146-157): self.state untouched; name the temperature its
                 // message names -- first evaluation of the trip, lowest zone
                 st |= ST_T_RANGE; frozen = true;
@@ -1765,16 +1795,16 @@ __device__ __forceinline__ void run_item(ArgPtr pa, const Lane &L, double *lds, 
                 dH = dHv;
                 dR = pt.rho;
                 bool clamped = false;
-                if (seg_any(L, pt.bad)) {
+                if (WT_RARE(seg_any(L, pt.bad))) {
                     st |= ST_T_RANGE_POST; frozen = true;
                     const unsigned long long m = __ballot(pt.bad) & L.segmask;
                     badval = __shfl(y0[STT], (int)__builtin_ctzll(m), 64);
                 } else {
                     dK = pt.kT; wrote_k = true;
                     // _enforce_physical_bounds reactor.py:526-541
-                    if (seg_any(L, y0[SPH] < 0 || y0[SPH] > 14)) { st |= ST_CLAMP_PH; y0[SPH] = fmin(fmax(y0[SPH], 0.0), 14.0); clamped = true; }
-                    if (seg_any(L, y0[SCL] < 0)) { st |= ST_CLAMP_CL; y0[SCL] = fmax(y0[SCL], 0.0); clamped = true; }
-                    if (seg_any(L, y0[STT] < 0 || y0[STT] > 100)) { st |= ST_CLAMP_T; y0[STT] = fmin(fmax(y0[STT], 0.0), 100.0); clamped = true; }
+                    if (WT_RARE(seg_any(L, y0[SPH] < 0 || y0[SPH] > 14))) { st |= ST_CLAMP_PH; y0[SPH] = fmin(fmax(y0[SPH], 0.0), 14.0); clamped = true; }
+                    if (WT_RARE(seg_any(L, y0[SCL] < 0))) { st |= ST_CLAMP_CL; y0[SCL] = fmax(y0[SCL], 0.0); clamped = true; }
+                    if (WT_RARE(seg_any(L, y0[STT] < 0 || y0[STT] > 100))) { st |= ST_CLAMP_T; y0[STT] = fmin(fmax(y0[STT], 0.0), 100.0); clamped = true; }
                     // f(y) of the last accepted point is f0 of the next outer step when nothing touched y
                     f_valid = fv && !clamped && !failed;
                 }
