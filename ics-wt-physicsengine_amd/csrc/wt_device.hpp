@@ -207,6 +207,54 @@ __device__ __forceinline__ double exp10_k(const KP &k, double x)
     return (x < k.t_lo) ? 0.0 : z;
 }
 
+// The Radau constants of the solver sections, fetched the same way (radau.py:11-40 values, see rc::)
+struct alignas(64) RTab {
+    double T00, T01, T02, T10, T11, T12, rtol, atol;                 // section Z: Z = T W, norm scales
+    double TI[9], mu_r, mu_cr, mu_ci, newton_tol, pad_n[3];           // section N: one Newton iteration
+    double E0, E1, E2, pad_e[5];                                      // section E: error estimate
+    double P[9], pad_a[7];                                            // section A: dense output of an accepted step
+    double C0, C1, pad_g[6];                                          // section G: initial guess of an attempt
+};
+static_assert(sizeof(RTab) == 56 * 8, "RTab layout");
+__host__ __device__ constexpr RTab default_rtab()
+{
+    RTab r{};
+    r.T00 = rc::T00; r.T01 = rc::T01; r.T02 = rc::T02; r.T10 = rc::T10; r.T11 = rc::T11; r.T12 = rc::T12; r.rtol = RTOL; r.atol = ATOL;
+    constexpr double ti[9] = {rc::TI00, rc::TI01, rc::TI02, rc::TI10, rc::TI11, rc::TI12, rc::TI20, rc::TI21, rc::TI22};
+    constexpr double pm[9] = {rc::P00, rc::P01, rc::P02, rc::P10, rc::P11, rc::P12, rc::P20, rc::P21, rc::P22};
+    for (int i = 0; i < 9; ++i) { r.TI[i] = ti[i]; r.P[i] = pm[i]; }
+    r.mu_r = rc::MU_REAL; r.mu_cr = rc::MU_CR; r.mu_ci = rc::MU_CI; r.newton_tol = rc::NEWTON_TOL;
+    r.E0 = rc::E0; r.E1 = rc::E1; r.E2 = rc::E2;
+    r.C0 = rc::C0; r.C1 = rc::C1;
+    return r;
+}
+struct KZ { double T00, T01, T02, T10, T11, T12, rtol, atol; };
+struct KN { double TI[9], mu_r, mu_cr, mu_ci, newton_tol; };
+struct KE { double E0, E1, E2; };
+struct KA { double P[9]; };
+struct KG { double C0, C1; };
+typedef const __attribute__((address_space(4))) RTab *RTabPtr;
+__device__ __forceinline__ KZ load_kz(RTabPtr t) { const d8 a = ((KVec)t)[0]; return {a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7]}; }
+__device__ __forceinline__ KN load_kn(RTabPtr t)
+{
+    const d8 a = ((KVec)t)[1], b = ((KVec)t)[2];
+    return {{a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], b[0]}, b[1], b[2], b[3], b[4]};
+}
+__device__ __forceinline__ KE load_ke(RTabPtr t) { const d8 a = ((KVec)t)[3]; return {a[0], a[1], a[2]}; }
+__device__ __forceinline__ KA load_ka(RTabPtr t)
+{
+    const d8 a = ((KVec)t)[4], b = ((KVec)t)[5];
+    return {{a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], b[0]}};
+}
+__device__ __forceinline__ KG load_kg(RTabPtr t) { const d8 a = ((KVec)t)[6]; return {a[0], a[1]}; }
+// The error estimate and the accept block keep literal constants: with loaded ones the compiler stops sharing their
+// common subexpressions and fuses the remaining ones differently (last-bit changes; measured, tools/bits_check.py).
+constexpr RTab RT0 = default_rtab();
+__device__ __forceinline__ KZ lit_kz() { return {RT0.T00, RT0.T01, RT0.T02, RT0.T10, RT0.T11, RT0.T12, RT0.rtol, RT0.atol}; }
+__device__ __forceinline__ KE lit_ke() { return {RT0.E0, RT0.E1, RT0.E2}; }
+__device__ __forceinline__ KA lit_ka() { return {{RT0.P[0], RT0.P[1], RT0.P[2], RT0.P[3], RT0.P[4], RT0.P[5], RT0.P[6], RT0.P[7], RT0.P[8]}}; }
+
+
 struct StepArgs {
     int64_t N;        // reactors in the ensemble (row stride of par / bc)
     int64_t r0, r1;   // stream schedule: this launch advances reactors [r0, r1); queue schedule: [0, N)
@@ -239,6 +287,7 @@ struct StepArgs {
     int64_t *trace; int trace_cap;   // optional item trace (tools/): worker, group, step0 | cnt << 32, start, end (100 MHz ticks)
     wts::SuiteArgs sens; // fused sensor suite + plant I/O (sens.on == 0: none)
     KTab kt;             // fp64 constants of the RHS sections (scalar loads)
+    RTab rt;             // ... of the solver sections
 };
 enum { Q_AVAIL = 0, Q_HEAD = 1, Q_TAIL = 2, Q_ERROR = 3, Q_TRACE = 4, Q_DONE = 5, Q_WORDS = 16 };
 
@@ -1470,15 +1519,16 @@ __device__ __forceinline__ void run_item(ArgPtr pa, const Lane &L, double *lds, 
                 err_old = error_norm;
                 have_old = true;
                 h_abs = h_abs_l * fct;
+                const KZ kz = lit_kz(); const KA ka = lit_ka();
 #pragma unroll
                 for (int q = 0; q < 3; ++q) {
-                    const double z0 = rc::T00 * W[0][q] + rc::T01 * W[1][q] + rc::T02 * W[2][q];
-                    const double z1 = rc::T10 * W[0][q] + rc::T11 * W[1][q] + rc::T12 * W[2][q];
+                    const double z0 = kz.T00 * W[0][q] + kz.T01 * W[1][q] + kz.T02 * W[2][q];
+                    const double z1 = kz.T10 * W[0][q] + kz.T11 * W[1][q] + kz.T12 * W[2][q];
                     const double z2 = W[0][q] + W[1][q];
                     y_old[q] = yc[q];
-                    Q[q][0] = z0 * rc::P00 + z1 * rc::P10 + z2 * rc::P20;  // Q = Z^T P  radau.py:541-543
-                    Q[q][1] = z0 * rc::P01 + z1 * rc::P11 + z2 * rc::P21;
-                    Q[q][2] = z0 * rc::P02 + z1 * rc::P12 + z2 * rc::P22;
+                    Q[q][0] = z0 * ka.P[0] + z1 * ka.P[3] + z2 * ka.P[6];  // Q = Z^T P  radau.py:541-543
+                    Q[q][1] = z0 * ka.P[1] + z1 * ka.P[4] + z2 * ka.P[7];
+                    Q[q][2] = z0 * ka.P[2] + z1 * ka.P[5] + z2 * ka.P[8];
                     yc[q] = yc[q] + z2;
                 }
                 sol_t_old = t; sol_h = t_new - t; have_sol = true;
@@ -1539,7 +1589,8 @@ __device__ __forceinline__ void run_item(ArgPtr pa, const Lane &L, double *lds, 
                                 for (int q = 0; q < 3; ++q) Z0[s][q] = 0.0;
                         } else {
                             const double isol = rcp(sol_h);
-                            const double cs[3] = {rc::C0, rc::C1, 1.0};
+                            const KG kg = load_kg(&fresh(pa)->rt);
+                            const double cs[3] = {kg.C0, kg.C1, 1.0};
 #pragma unroll
                             for (int s = 0; s < 3; ++s) {
                                 const double x = ((t + h * cs[s]) - sol_t_old) * isol;
@@ -1549,11 +1600,12 @@ __device__ __forceinline__ void run_item(ArgPtr pa, const Lane &L, double *lds, 
                                     Z0[s][q] = ((Q[q][0] * x + Q[q][1] * p1 + Q[q][2] * p2) + y_old[q]) - yc[q];
                             }
                         }
+                        const KN kn0 = load_kn(&fresh(pa)->rt);
 #pragma unroll
                         for (int q = 0; q < 3; ++q) {
-                            W[0][q] = rc::TI00 * Z0[0][q] + rc::TI01 * Z0[1][q] + rc::TI02 * Z0[2][q];
-                            W[1][q] = rc::TI10 * Z0[0][q] + rc::TI11 * Z0[1][q] + rc::TI12 * Z0[2][q];
-                            W[2][q] = rc::TI20 * Z0[0][q] + rc::TI21 * Z0[1][q] + rc::TI22 * Z0[2][q];
+                            W[0][q] = kn0.TI[0] * Z0[0][q] + kn0.TI[1] * Z0[1][q] + kn0.TI[2] * Z0[2][q];
+                            W[1][q] = kn0.TI[3] * Z0[0][q] + kn0.TI[4] * Z0[1][q] + kn0.TI[5] * Z0[2][q];
+                            W[2][q] = kn0.TI[6] * Z0[0][q] + kn0.TI[7] * Z0[1][q] + kn0.TI[8] * Z0[2][q];
                         }
                         kk = 0; have_norm_old = false; have_rate = false; rate = 0.0;
                         phase = PH_NEWTON;
@@ -1576,10 +1628,11 @@ __device__ __forceinline__ void run_item(ArgPtr pa, const Lane &L, double *lds, 
                 const bool eval3 = newton && pend_f;
                 double ye[3][3], Fe[3][3];
                 // Z = T W (radau.py:124): Z[2] = W0 + W1
+                const KZ kzp = load_kz(&fresh(pa)->rt);
 #pragma unroll
                 for (int q = 0; q < 3; ++q) {
-                    const double z0 = rc::T00 * W[0][q] + rc::T01 * W[1][q] + rc::T02 * W[2][q];
-                    const double z1 = rc::T10 * W[0][q] + rc::T11 * W[1][q] + rc::T12 * W[2][q];
+                    const double z0 = kzp.T00 * W[0][q] + kzp.T01 * W[1][q] + kzp.T02 * W[2][q];
+                    const double z1 = kzp.T10 * W[0][q] + kzp.T11 * W[1][q] + kzp.T12 * W[2][q];
                     const double z2 = W[0][q] + W[1][q];
                     double p0 = yc[q];                                        // PH_OUTER_BEGIN, PH_FNEW
                     if (phase == PH_F1) p0 = aux[q];
@@ -1654,14 +1707,16 @@ __device__ __forceinline__ void run_item(ArgPtr pa, const Lane &L, double *lds, 
                         diverged = true;
                     } else {
                         const double ih = rcp(h);
-                        const double M_real = rc::MU_REAL * ih, Mcr = rc::MU_CR * ih, Mci = rc::MU_CI * ih;
+                        const RTabPtr rt = &fresh(pa)->rt;
+                        const KN kn = load_kn(rt); const KZ kz = load_kz(rt);
+                        const double M_real = kn.mu_r * ih, Mcr = kn.mu_cr * ih, Mci = kn.mu_ci * ih;
                         double fr[3], fcr[3], fci[3], scale[3];
 #pragma unroll
                         for (int q = 0; q < 3; ++q) {
-                            scale[q] = ATOL + fabs(yc[q]) * RTOL;
-                            fr[q] = (Fe[0][q] * rc::TI00 + Fe[1][q] * rc::TI01 + Fe[2][q] * rc::TI02) - M_real * W[0][q];
-                            const double re = Fe[0][q] * rc::TI10 + Fe[1][q] * rc::TI11 + Fe[2][q] * rc::TI12;
-                            const double im = Fe[0][q] * rc::TI20 + Fe[1][q] * rc::TI21 + Fe[2][q] * rc::TI22;
+                            scale[q] = kz.atol + fabs(yc[q]) * kz.rtol;
+                            fr[q] = (Fe[0][q] * kn.TI[0] + Fe[1][q] * kn.TI[1] + Fe[2][q] * kn.TI[2]) - M_real * W[0][q];
+                            const double re = Fe[0][q] * kn.TI[3] + Fe[1][q] * kn.TI[4] + Fe[2][q] * kn.TI[5];
+                            const double im = Fe[0][q] * kn.TI[6] + Fe[1][q] * kn.TI[7] + Fe[2][q] * kn.TI[8];
                             fcr[q] = re - (Mcr * W[1][q] - Mci * W[2][q]);
                             fci[q] = im - (Mcr * W[2][q] + Mci * W[1][q]);
                         }
@@ -1676,12 +1731,12 @@ __device__ __forceinline__ void run_item(ArgPtr pa, const Lane &L, double *lds, 
                         const double dW_norm = sqrt_k(div_by(seg_sum<ROW>(L, ssum), L.d9n));
                         if (have_norm_old) { rate = dW_norm * rcp(dW_norm_old); have_rate = true; }
                         const double i1r = rcp(1 - rate);
-                        if (have_rate && (rate >= 1 || powi6(rate, NEWTON_MAXITER - kk) * i1r * dW_norm > rc::NEWTON_TOL)) {
+                        if (have_rate && (rate >= 1 || powi6(rate, NEWTON_MAXITER - kk) * i1r * dW_norm > kn.newton_tol)) {
                             diverged = true;
                         } else {
 #pragma unroll
                             for (int q = 0; q < 3; ++q) { W[0][q] += fr[q]; W[1][q] += fcr[q]; W[2][q] += fci[q]; }
-                            if (dW_norm == 0 || (have_rate && rate * i1r * dW_norm < rc::NEWTON_TOL)) conv = true;
+                            if (dW_norm == 0 || (have_rate && rate * i1r * dW_norm < kn.newton_tol)) conv = true;
                             dW_norm_old = dW_norm; have_norm_old = true;
                         }
                     }
@@ -1695,14 +1750,15 @@ __device__ __forceinline__ void run_item(ArgPtr pa, const Lane &L, double *lds, 
                         // ---- error estimate radau.py:477-487
                         double err[3], esc[3];
                         const double ih_e = rcp(h);
+                        const KZ kze = lit_kz(); const KE ke = lit_ke();
 #pragma unroll
                         for (int q = 0; q < 3; ++q) {
-                            const double z0 = rc::T00 * W[0][q] + rc::T01 * W[1][q] + rc::T02 * W[2][q];
-                            const double z1 = rc::T10 * W[0][q] + rc::T11 * W[1][q] + rc::T12 * W[2][q];
+                            const double z0 = kze.T00 * W[0][q] + kze.T01 * W[1][q] + kze.T02 * W[2][q];
+                            const double z1 = kze.T10 * W[0][q] + kze.T11 * W[1][q] + kze.T12 * W[2][q];
                             const double z2 = W[0][q] + W[1][q];
-                            const double ZE = (z0 * rc::E0 + z1 * rc::E1 + z2 * rc::E2) * ih_e;
+                            const double ZE = (z0 * ke.E0 + z1 * ke.E1 + z2 * ke.E2) * ih_e;
                             err[q] = f[q] + ZE;
-                            esc[q] = ATOL + fmax(fabs(yc[q]), fabs(yc[q] + z2)) * RTOL;
+                            esc[q] = kze.atol + fmax(fabs(yc[q]), fabs(yc[q] + z2)) * kze.rtol;
                         }
                         solve_real<ROW, LV>(L, J, F, err);
                         error_norm = rms3<ROW>(L, err, esc);
@@ -1720,14 +1776,15 @@ __device__ __forceinline__ void run_item(ArgPtr pa, const Lane &L, double *lds, 
                 } else if (WT_RARE(phase == PH_ERR_REFINE)) {
                     double err[3], esc[3];
                     const double ih_e = rcp(h);
+                    const KZ kze = lit_kz(); const KE ke = lit_ke();
 #pragma unroll
                     for (int q = 0; q < 3; ++q) {
-                        const double z0 = rc::T00 * W[0][q] + rc::T01 * W[1][q] + rc::T02 * W[2][q];
-                        const double z1 = rc::T10 * W[0][q] + rc::T11 * W[1][q] + rc::T12 * W[2][q];
+                        const double z0 = kze.T00 * W[0][q] + kze.T01 * W[1][q] + kze.T02 * W[2][q];
+                        const double z1 = kze.T10 * W[0][q] + kze.T11 * W[1][q] + kze.T12 * W[2][q];
                         const double z2 = W[0][q] + W[1][q];
-                        const double ZE = (z0 * rc::E0 + z1 * rc::E1 + z2 * rc::E2) * ih_e;
+                        const double ZE = (z0 * ke.E0 + z1 * ke.E1 + z2 * ke.E2) * ih_e;
                         err[q] = Fe[0][q] + ZE;
-                        esc[q] = ATOL + fmax(fabs(yc[q]), fabs(yc[q] + z2)) * RTOL;
+                        esc[q] = kze.atol + fmax(fabs(yc[q]), fabs(yc[q] + z2)) * kze.rtol;
                     }
                     solve_real<ROW, LV>(L, J, F, err);
                     error_norm = rms3<ROW>(L, err, esc);

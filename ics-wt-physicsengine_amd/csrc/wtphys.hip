@@ -108,7 +108,7 @@ wt::StepArgs make_args(const wt_ensemble *h, double dt, int n_steps, int first_s
     a.dt = dt; a.n_steps = n_steps; a.first_step = first_step; a.call_steps = call_steps; a.step_limit = h->step_limit;
     a.q_ctrl = nullptr; a.q_slots = nullptr; a.q_next = nullptr; a.q_cap = 0; a.item_steps = n_steps; a.n_groups = (int)h->n_groups;
     a.trace = h->trace; a.trace_cap = h->trace_cap;
-    a.kt = wt::default_ktab();
+    a.kt = wt::default_ktab(); a.rt = wt::default_rtab();
     wts::SuiteArgs &s = a.sens;
     memset(&s, 0, sizeof s);
     s.on = h->sensors_on ? 1 : 0; s.plc_on = h->plc_on ? 1 : 0; s.scan_every = scan_every > 0 ? scan_every : 1;
