@@ -1,10 +1,11 @@
-"""Batched carbonate-system pH solver (the reference's AqueousChemistry.calculate_pH,
-chemistry.py:193-398), one Newton-Raphson solve per element on the GPU."""
+"""Carbonate-buffered water chemistry: the batched equilibrium-pH solve (the reference's
+``AqueousChemistry.calculate_pH``, chemistry.py:193-398) runs on the GPU, one Newton-Raphson iteration chain per
+element (``ph_solve_kernel`` in csrc/wt_device.hpp); the closed forms around it are ``params`` routines."""
 from __future__ import annotations
 
 import ctypes as C
 from dataclasses import dataclass
-from typing import Tuple
+from typing import Dict, Tuple
 
 import numpy as np
 
@@ -13,16 +14,14 @@ from . import _native, params
 
 @dataclass
 class BufferSystem:
-    """chemistry.py:54-80."""
-    alkalinity: float
-    total_carbonate: float
-    temperature: float = 20.0
+    alkalinity: float           # [mg/L as CaCO3]
+    total_carbonate: float      # [mmol/L]
+    temperature: float = 20.0   # [degC]
 
     def validate(self) -> None:
-        if self.alkalinity < 0:
-            raise ValueError(f"Alkalinity cannot be negative: {self.alkalinity}")
-        if self.total_carbonate < 0:
-            raise ValueError(f"Total carbonate cannot be negative: {self.total_carbonate}")
+        for name in ("alkalinity", "total_carbonate"):
+            if getattr(self, name) < 0:
+                raise ValueError(f"{name.replace('_', ' ').capitalize()} cannot be negative: {getattr(self, name)}")
 
 
 def solve_pH(alkalinity, total_carbonate, temperature, initial_guess=7.0, tolerance: float = 1e-6,
@@ -37,9 +36,8 @@ def solve_pH(alkalinity, total_carbonate, temperature, initial_guess=7.0, tolera
     shape = alk.shape
     alk, ct, T, g = [np.ascontiguousarray(x.ravel()) for x in (alk, ct, T, g)]
     n = alk.size
-    Kw = np.ascontiguousarray(params.water_ionization_constant(T))
-    Ka1 = np.ascontiguousarray(params._pow10_neg(params.carbonate_pKa(T, 1)))
-    Ka2 = np.ascontiguousarray(params._pow10_neg(params.carbonate_pKa(T, 2)))
+    eq = params.equilibrium_constants(T)
+    Kw, Ka1, Ka2 = (np.ascontiguousarray(eq[k]) for k in ("Kw", "Ka1", "Ka2"))
     ct_mol = np.ascontiguousarray(ct / 1000.0)
     pH = np.empty(n)
     it = np.zeros(n, dtype=np.int32)
@@ -53,81 +51,67 @@ def solve_pH(alkalinity, total_carbonate, temperature, initial_guess=7.0, tolera
 
 
 class AqueousChemistry:
-    """Scalar convenience wrapper with the reference's method names and errors."""
+    """One buffer's equilibrium constants (frozen at the buffer temperature: the same numbers the ensemble uploads as
+    that reactor's constants) under the reference's attribute and method names.  Methods take a pH (or an array of
+    them) and evaluate the column-wise routines of ``params``."""
 
     PH_TOLERANCE = 1e-6
     MAX_ITERATIONS = 100
+    CONSTANTS = ("Kw", "pKw", "pKa1", "Ka1", "pKa2", "Ka2", "pKa_HOCl", "Ka_HOCl")
 
     def __init__(self, buffer_system: BufferSystem, device: int = 0):
-        buffer_system.validate()
-        self.buffer = buffer_system
-        self.device = device
-        # chemistry.py:116-132: equilibrium constants frozen at the buffer's temperature (the same
-        # values params.derive_constants uploads as the reactor's constants)
         from .physics import TemperatureDependentKinetics
+        buffer_system.validate()
+        self.buffer, self.device = buffer_system, device
         self.thermo = TemperatureDependentKinetics()
-        T = buffer_system.temperature
-        self.Kw = self.thermo.water_ionization_constant(T)
-        self.pKw = -np.log10(self.Kw)
-        self.pKa1 = self.thermo.carbonate_pKa(T, dissociation=1)
-        self.Ka1 = 10 ** (-self.pKa1)
-        self.pKa2 = self.thermo.carbonate_pKa(T, dissociation=2)
-        self.Ka2 = 10 ** (-self.pKa2)
-        self.pKa_HOCl = 7.5 + 0.01 * (T - 25.0)
-        self.Ka_HOCl = 10 ** (-self.pKa_HOCl)
+        self.thermo.celsius_to_kelvin(buffer_system.temperature)
+        frozen = params.equilibrium_constants(np.array([float(buffer_system.temperature)]))
+        for name in self.CONSTANTS:
+            setattr(self, name, float(frozen[name][0]))
 
-    # scalar closed forms of one reactor's chemistry (diagnostics, validators); inside step() the same
-    # expressions run per zone per RHS evaluation in the kernel (wt_device.hpp prop_pH)
-    def H_from_pH(self, pH: float) -> float:
-        return 10 ** (-pH)
+    @staticmethod
+    def _out(value):
+        value = np.asarray(value)
+        return float(value) if value.ndim == 0 else value
 
-    def pH_from_H(self, H: float) -> float:
-        return -np.log10(H)
+    def H_from_pH(self, pH):
+        return self._out(params._pow10_neg(pH))
 
-    def alpha_carbonate(self, pH: float):
-        """chemistry.py:158-191."""
-        H = self.H_from_pH(pH)
-        D = H ** 2 + self.Ka1 * H + self.Ka1 * self.Ka2
-        return H ** 2 / D, (self.Ka1 * H) / D, (self.Ka1 * self.Ka2) / D
+    def pH_from_H(self, H):
+        return self._out(-np.log10(H))
 
-    def buffering_capacity(self, pH: float) -> float:
-        """chemistry.py:400-437."""
-        H = self.H_from_pH(pH)
-        beta_water = 2.303 * (H + self.Kw / H)
-        C_T_mol = self.buffer.total_carbonate / 1000.0
-        a0, a1, a2 = self.alpha_carbonate(pH)
-        return beta_water + 2.303 * C_T_mol * (a0 * a1 + 4 * a1 * a2 + a0 * a2)
+    def alpha_carbonate(self, pH):
+        return tuple(self._out(a) for a in params.carbonate_fractions(params._pow10_neg(pH), self.Ka1, self.Ka2))
 
-    def chlorine_speciation(self, total_chlorine_mg_L: float, pH: float):
-        """chemistry.py:439-481."""
-        H = self.H_from_pH(pH)
-        a_HOCl = H / (H + self.Ka_HOCl)
-        a_OCl = self.Ka_HOCl / (H + self.Ka_HOCl)
-        return {"HOCl": a_HOCl * total_chlorine_mg_L, "OCl": a_OCl * total_chlorine_mg_L, "HOCl_fraction": a_HOCl,
-                "OCl_fraction": a_OCl, "effective_disinfection": a_HOCl}
+    def buffering_capacity(self, pH):
+        return self._out(params.buffer_capacity(params._pow10_neg(pH), self.Kw, self.Ka1, self.Ka2,
+                                                self.buffer.total_carbonate / 1000.0))
 
-    def pH_dependent_chlorine_decay_factor(self, pH: float) -> float:
-        """chemistry.py:483-523."""
-        H = self.H_from_pH(pH)
-        return H / (H + self.Ka_HOCl) * 1.0 + self.Ka_HOCl / (H + self.Ka_HOCl) * 0.02
+    def chlorine_speciation(self, total_chlorine_mg_L, pH) -> Dict[str, float]:
+        hocl, ocl = (self._out(a) for a in params.hypochlorous_fraction(params._pow10_neg(pH), self.Ka_HOCl))
+        return {"HOCl": hocl * total_chlorine_mg_L, "OCl": ocl * total_chlorine_mg_L, "HOCl_fraction": hocl,
+                "OCl_fraction": ocl, "effective_disinfection": hocl}
 
-    def calculate_pH(self, initial_guess: float = 7.0, tolerance: float = PH_TOLERANCE,
-                     max_iter: int = MAX_ITERATIONS) -> float:
-        pH, it, rc = solve_pH(self.buffer.alkalinity, self.buffer.total_carbonate, self.buffer.temperature,
-                              initial_guess, tolerance, max_iter, self.device)
-        if int(rc) == 1:
-            raise RuntimeError(f"Derivative too small at pH={float(pH):.3f}, cannot continue")
-        if int(rc) == 2:
-            raise RuntimeError(f"pH calculation did not converge after {max_iter} iterations. "
-                               f"Final pH={float(pH):.3f}")
+    def pH_dependent_chlorine_decay_factor(self, pH):
+        return self._out(params.chlorine_decay_factor(params._pow10_neg(pH), self.Ka_HOCl))
+
+    def calculate_pH(self, initial_guess: float = 7.0, tolerance: float = PH_TOLERANCE, max_iter: int = MAX_ITERATIONS) -> float:
+        b = self.buffer
+        pH, _, rc = solve_pH(b.alkalinity, b.total_carbonate, b.temperature, initial_guess, tolerance, max_iter, self.device)
+        failure = {1: f"Derivative too small at pH={float(pH):.3f}, cannot continue",
+                   2: f"pH calculation did not converge after {max_iter} iterations. Final pH={float(pH):.3f}"}.get(int(rc))
+        if failure:
+            raise RuntimeError(failure)
         return float(pH)
 
+    def _dosed(self, alkalinity_shift: float, current_pH: float) -> float:
+        """Equilibrium pH after the alkalinity moved by ``alkalinity_shift`` mg/L as CaCO3 (50 g per equivalent)."""
+        b = self.buffer
+        return AqueousChemistry(BufferSystem(b.alkalinity + alkalinity_shift, b.total_carbonate, b.temperature),
+                                self.device).calculate_pH(initial_guess=current_pH)
+
     def add_acid(self, volume_L: float, acid_mol: float, current_pH: float) -> float:
-        delta_alk = -(acid_mol / volume_L) * 50000.0            # chemistry.py:355-358
-        nb = BufferSystem(self.buffer.alkalinity + delta_alk, self.buffer.total_carbonate, self.buffer.temperature)
-        return AqueousChemistry(nb, self.device).calculate_pH(initial_guess=current_pH)
+        return self._dosed(-(acid_mol / volume_L) * 50000.0, current_pH)       # chemistry.py:355-358
 
     def add_base(self, volume_L: float, base_mol: float, current_pH: float) -> float:
-        delta_alk = (base_mol / volume_L) * 50000.0             # chemistry.py:386-387
-        nb = BufferSystem(self.buffer.alkalinity + delta_alk, self.buffer.total_carbonate, self.buffer.temperature)
-        return AqueousChemistry(nb, self.device).calculate_pH(initial_guess=current_pH)
+        return self._dosed((base_mol / volume_L) * 50000.0, current_pH)        # chemistry.py:386-387
