@@ -34,9 +34,14 @@ class SolverStats(C.Structure):
                 ("nsteps", C.c_int32), ("nrej", C.c_int32)]
 
 
+# what libwtphys.so is built from: wtphys.hip and exactly the headers it includes
+# (tests/test_host_api.py::test_build_staleness_list_matches_the_includes)
+BUILD_SOURCES = ("wtphys.hip", "wt_device.hpp", "wt_sensors.hpp", "wt_plc.hpp", "wt_diag.hpp", "wt_place.hpp")
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     """Compile csrc/wtphys.hip for gfx950 into csrc/libwtphys.so (hipcc)."""
-    srcs = [os.path.join(CSRC, f) for f in ("wtphys.hip", "wt_device.hpp", "wt_triad.hpp", "wt_sensors.hpp", "wt_plc.hpp", "wt_diag.hpp")]
+    srcs = [os.path.join(CSRC, f) for f in BUILD_SOURCES]
     srcs.append(os.path.join(os.path.dirname(_PKG), "include", "wtphys.h"))
     stale = (not os.path.exists(LIB_PATH)
              or os.path.getmtime(LIB_PATH) < max(os.path.getmtime(s) for s in srcs))
@@ -80,6 +85,8 @@ def lib():
     L.wt_ensemble_set_step_limit.argtypes = [vp, C.c_int]
     L.wt_ensemble_set_placement.argtypes = [vp, C.c_int]
     L.wt_ensemble_get_placement.argtypes = [vp, ip, i32p]
+    L.wt_ensemble_placement_info.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    L.wt_ensemble_placement_info.restype = C.c_int
     L.wt_ensemble_launch_timing.argtypes = [vp, C.c_int]
     L.wt_ensemble_launch_stats.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.wt_ensemble_synchronize.argtypes = [vp]

@@ -237,6 +237,7 @@ class ReactorEnsemble:
                        np.zeros(self.n_reactors))
         self._boundary: Optional[np.ndarray] = None
         self._device_boundary_moved = False     # the command path (plant I/O) rewrites the device's boundary block
+        self._plant_io = False
 
     # -- lifetime
     def close(self) -> None:
@@ -279,6 +280,8 @@ class ReactorEnsemble:
             if e.code == _native.WT_E_ARG:
                 raise ValueError(e.message) from None
             raise
+        if getattr(self, "_plant_io", False):
+            self._device_boundary_moved = True    # every PLC scan rewrites the device's boundary rows 0 / 4 / 6
         return self.state if download else None
 
     def set_schedule(self, n_streams: int = 0, chunk_steps: int = 50) -> None:
@@ -294,8 +297,11 @@ class ReactorEnsemble:
         mode = {0: "streams", 1: "queue"}.get(m.value, str(m.value))
         pm = C.c_int(0)
         _native.check(_native.lib().wt_ensemble_get_placement(self._h, C.byref(pm), None))
+        rd, hs = C.c_int64(0), C.c_int64(0)
+        _native.check(_native.lib().wt_ensemble_placement_info(self._h, C.byref(rd), C.byref(hs)))
         return {"mode": mode, "streams": s.value, "chunk": c.value, "workers": w.value,
-                "kernel": "wt::step_kernel", "placement": "adaptive" if pm.value else "identity"}
+                "kernel": "wt::step_kernel", "placement": "adaptive" if pm.value else "identity",
+                "redeals": int(rd.value), "cost_history_steps": int(hs.value)}
 
     def item_steps(self, n_steps: int) -> int:
         """Outer steps a reactor's state stays in registers before it returns to memory in a call of ``n_steps``."""
@@ -425,6 +431,7 @@ class ReactorEnsemble:
         input image is refreshed from the sensor readings (``update_modbus_inputs``) and the holding image
         is validated into the boundary conditions (``read_modbus_commands`` + ``apply_boundary_conditions``)."""
         _native.check(_native.lib().wt_ensemble_plc_enable(self._h))
+        self._plant_io = True
         self._device_boundary_moved = True
 
     @staticmethod
@@ -546,11 +553,18 @@ class IntegratedCSTR:
     """Drop-in for the reference class of the same name (reactor.py:189-611),
     backed by a one-reactor ensemble on the GPU."""
 
-    def __init__(self, config: ReactorConfiguration, device: int = 0):
+    #: Radau step attempts per outer step before the solve is given up with a warning.  scipy's solve_ivp has no such
+    #: limit, but the step kernel cannot be cancelled: where the solution slides along the 8 degC density jump the
+    #: reference needs millions of internal steps (hours), and an unbounded device solve looks like a hang from the
+    #: host.  Ten million attempts is far beyond anything a finite reference run was seen to need; pass
+    #: ``step_limit=0`` for the reference's unbounded behaviour.
+    DEFAULT_STEP_LIMIT = 10_000_000
+
+    def __init__(self, config: ReactorConfiguration, device: int = 0, step_limit: Optional[int] = None):
         config.validate()
         self.config = config
         self._ens = ReactorEnsemble([config], device=device, validate=False)
-        self._ens.set_step_limit(0)      # scipy's solve_ivp has no attempt limit (ReactorEnsemble keeps a guard)
+        self._ens.set_step_limit(self.DEFAULT_STEP_LIMIT if step_limit is None else int(step_limit))
         self._last = None                # (pH, chlorine, temperature, time) as the device holds them, when known
         n = config.n_zones
         self._initialize_physics_modules()

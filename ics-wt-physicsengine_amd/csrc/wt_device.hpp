@@ -1424,7 +1424,7 @@ __device__ __forceinline__ void run_item(ArgPtr pa, const Lane &L, double *lds, 
     double flow_used = 0;                             // ReactorState.flow_rate: the flows of the last step taken
     uint32_t st = 0;
     bool frozen = !present, f_valid = false, wrote_k = false, raised = false;
-    int steps_done = 0, cost_acc = 0;
+    int steps_done = 0, reads_done = 0, cost_acc = 0;
     SolverCounters last_cnt = {0, 0, 0, 0, 0};
     int diag_trips = 0, diag_newton = 0;              // per item: 32 bits are plenty
 #ifdef WT_STAMPS  // block-execution counters cost a ballot and a branch each per trip: diagnostic builds only
@@ -1878,6 +1878,7 @@ __device__ __forceinline__ void run_item(ArgPtr pa, const Lane &L, double *lds, 
                 const bool live = stepped && !(st & ST_T_RANGE_POST);     // the reference's loop stops where step() raises
                 if (L.z == 0) {
                     io.stepped[seg] = live ? 1 : 0;
+                    if (live) reads_done++;
                     io.t_after[seg] = t_out;
                     io.tap[0][seg] = (float)y0[SPH]; io.tap[2][seg] = (float)y0[SCL]; io.tap[4][seg] = (float)y0[STT];
                     io.tap[6][seg] = (float)flow_used;
@@ -1931,7 +1932,7 @@ __device__ __forceinline__ void run_item(ArgPtr pa, const Lane &L, double *lds, 
                     int32_t *o = c->stats + r * 5;
                     o[0] = last_cnt.nfev; o[1] = last_cnt.njev; o[2] = last_cnt.nlu; o[3] = last_cnt.nsteps; o[4] = last_cnt.nrej;
                 }
-                if (sens_on && c->sens.hist_value) c->sens.hist_pos[r] = hist0[seg] + steps_done;
+                if (sens_on && c->sens.hist_value) c->sens.hist_pos[r] = hist0[seg] + reads_done;
             }
             c->status[r] = st;
             if (st & (ST_T_RANGE | ST_T_RANGE_POST)) c->bad_T[r] = badval;
@@ -2021,6 +2022,42 @@ __global__ __launch_bounds__(64) void step_kernel(const StepArgs a_unused)
         }
         hold = __builtin_amdgcn_readfirstlane(hold);
         group = queue_next(pa, more ? group : -1, hold != 0, exchanged);
+    }
+}
+
+// After a queue-schedule launch: every group must have advanced by the launch's step count and the hand-off must
+// not have timed out; anything else is recorded in a word that survives the next launch's queue reset and that every
+// download path reports (a short-changed group must not pass as WT_OK).
+struct QueueCheckArgs { const int32_t *q_ctrl, *q_next; int n_groups, n_steps; int32_t *sticky; };
+__global__ __launch_bounds__(256) void queue_check_kernel(const QueueCheckArgs a)
+{
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    int bad = 0;
+    if (g < a.n_groups && a.q_next[g] != a.n_steps) bad = 2;
+    if (g == 0 && a.q_ctrl[Q_ERROR] != 0) bad |= 1;
+    if (bad) atomicOr(a.sticky, bad);
+}
+
+// One contiguous image of a small ensemble's state for a single device-to-host copy:
+// [pH | Cl | T | H | rho | k] (N n doubles each), [time | flow] (N doubles each), status (N words), sticky word.
+struct SnapshotArgs {
+    int64_t cnt, N;
+    const double *pH, *Cl, *T, *dH, *dRho, *dK, *time, *flow; const uint32_t *status; const int32_t *sticky;
+    double *out;
+};
+__global__ __launch_bounds__(256) void snapshot_pack_kernel(const SnapshotArgs a)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < a.cnt) {
+        a.out[i] = a.pH[i]; a.out[a.cnt + i] = a.Cl[i]; a.out[2 * a.cnt + i] = a.T[i];
+        a.out[3 * a.cnt + i] = a.dH[i]; a.out[4 * a.cnt + i] = a.dRho[i]; a.out[5 * a.cnt + i] = a.dK[i];
+    }
+    if (i < a.N) {
+        double *tail = a.out + 6 * a.cnt;
+        tail[i] = a.time[i]; tail[a.N + i] = a.flow[i];
+        uint32_t *w = reinterpret_cast<uint32_t *>(tail + 2 * a.N);
+        w[i] = a.status[i];
+        if (i == 0) w[a.N] = (uint32_t)*a.sticky;
     }
 }
 

@@ -2,9 +2,6 @@
 // Owns device memory behind an opaque handle, uploads the SoA constant / boundary
 // blocks, launches the gfx950 kernels of wt_device.hpp on the handle's stream.
 #include "wt_device.hpp"
-#ifdef WT_TRIAD   // experiment builds only (tools/triad_check.py): one wavefront per species, DESIGN.md section 8
-#include "wt_triad.hpp"
-#endif
 #include "wt_diag.hpp"
 #include "wt_place.hpp"
 #include "../../include/wtphys.h"
@@ -15,6 +12,8 @@
 #include <cstring>
 #include <string>
 #include <vector>
+
+#define WT_SNAPSHOT_PACK_MAX (256u * 1024u)   /* ensembles up to this image size download as one packed copy */
 
 namespace {
 
@@ -63,7 +62,6 @@ struct wt_ensemble {
     int q_cap = 0, q_workers = 0;
     int64_t n_groups = 0;
     int sched_mode = WT_SCHED_QUEUE;
-    bool triad = false;           // experiment builds (-DWT_TRIAD): three wavefronts per group, one per species (wt_triad.hpp)
     int64_t *trace = nullptr; int trace_cap = 0;   // developer item trace (wt_ensemble_item_trace)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool have_bc = false, have_state = false;
@@ -71,6 +69,15 @@ struct wt_ensemble {
     // (wavefront-group, next few outer steps) items from a device-side FIFO.  WT_SCHED_STREAMS (round-1
     // schedule, kept for comparison): n_sub contiguous reactor ranges on their own HIP streams, launches of
     // at most chunk_steps outer steps.  chunk_steps is also the PLC scan interval.
+    // developer knobs (tools/), read from the environment once at creation: WT_Q_ITEM (outer steps per work item),
+    // WT_PLACE_MIN (history before a re-deal), WT_Q_TICKETS (forces the launch split), WT_FULL_WAVES
+    int knob_item = 0; int64_t knob_place_min = 0, knob_tickets = 0;
+    // sticky record of a launch that did not advance every group (device word + pinned host mirror)
+    int32_t *q_sticky = nullptr;
+    // one contiguous snapshot of a small ensemble: packed on the device, one copy into pinned memory
+    void *snap_dev = nullptr, *snap_host = nullptr; size_t snap_bytes = 0;
+    int32_t *err_host = nullptr;   // pinned: the sticky word of ensembles too large for the packed snapshot
+    int64_t redeals = 0;          // times the slots were re-dealt (bench.py reports it)
     int n_sub = 1, chunk_steps = WT_DEFAULT_CHUNK;
     int step_limit = 2000;    // attempts per outer step before a reactor is given up (reference: unlimited)
     hipStream_t sub_stream[WT_MAX_STREAMS] = {};
@@ -158,33 +165,9 @@ template <class F> void with_step_kernel(const wt_ensemble *h, F &&f)
     const int n = h->n;
 #ifdef WT_ONLY_LV3   // scratch builds for kernel tuning: n in 5..8 only (n = 8 takes the row-shift variant)
     (void)n;
-#ifdef WT_TRIAD
-    if (h->triad) { f(wt::tri::triad_kernel<3, true>, 192); return; }
-#endif
     f(wt::step_kernel<3, true>, 64);
 #else
     const int lv = levels_for(n);
-#ifdef WT_TRIAD
-    if (h->triad) {
-        if (row_mode(n)) {
-            switch (lv) {
-            case 1: f(wt::tri::triad_kernel<1, true>, 192); break;
-            case 2: f(wt::tri::triad_kernel<2, true>, 192); break;
-            case 3: f(wt::tri::triad_kernel<3, true>, 192); break;
-            default: f(wt::tri::triad_kernel<4, true>, 192); break;
-            }
-        } else {
-            switch (lv) {
-            case 2: f(wt::tri::triad_kernel<2, false>, 192); break;
-            case 3: f(wt::tri::triad_kernel<3, false>, 192); break;
-            case 4: f(wt::tri::triad_kernel<4, false>, 192); break;
-            case 5: f(wt::tri::triad_kernel<5, false>, 192); break;
-            default: f(wt::tri::triad_kernel<6, false>, 192); break;
-            }
-        }
-        return;
-    }
-#endif
     if (row_mode(n)) { // n in {2,4,8,16}: every cross-lane move is a DPP row operation
         switch (lv) {
         case 1: f(wt::step_kernel<1, true>, 64); break;
@@ -228,12 +211,12 @@ void launch_step(wt_ensemble *h, const wt::StepArgs &a, unsigned grid, hipStream
 // Outer steps per work item of the queue schedule.  A group changes hands at item boundaries, which costs a few
 // microseconds (state out and in, release / acquire), so not every step -- but often enough that the groups
 // sharing the workers take turns at least half a dozen times; at most 32 steps.
-int queue_item_steps(int n_steps)
+int queue_item_steps(const wt_ensemble *h, int n_steps)
 {
     int item = n_steps / 6;
     if (item > 32) item = 32;
     if (item < 1) item = 1;
-    if (const char *e = getenv("WT_Q_ITEM")) item = atoi(e) > 0 ? atoi(e) : item;          // tuning knob (tools/)
+    if (h->knob_item > 0) item = h->knob_item;
     return item;
 }
 
@@ -250,6 +233,15 @@ int queue_workers(const wt_ensemble *h)
     if (per_cu <= 0) per_cu = 4;
     const int64_t cap = (int64_t)cus * per_cu;
     return (int)(h->n_groups < cap ? h->n_groups : cap);
+}
+
+const char *k_incomplete = "a step launch did not advance every wavefront-group (work-queue hand-off timed out or a group was left behind); the state on the device is incomplete";
+
+// queue the copy of the sticky launch-error word (pinned destination) behind what is already on the stream
+int fetch_sticky(wt_ensemble *h)
+{
+    HIP_TRY(hipMemcpyAsync(h->err_host, h->q_sticky, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    return WT_OK;
 }
 
 } // namespace
@@ -283,9 +275,6 @@ int wt_ensemble_create(int64_t n_reactors, int n_zones, int device, const double
     HIP_TRY(hipSetDevice(device));
     wt_ensemble *h = new wt_ensemble();
     h->N = n_reactors; h->n = n_zones; h->R = 64 / n_zones; h->device = device;
-#ifdef WT_TRIAD
-    if (const char *e = getenv("WT_KERNEL")) h->triad = std::string(e) == "triad";
-#endif
     {   // A small ensemble is spread over all SIMDs rather than packed into full wavefronts: a wavefront costs what
         // its slowest reactor costs, so fewer reactors per wavefront is faster as long as every wavefront still
         // finds a SIMD (about 4 per CU).  Results do not depend on it (reactors never interact).
@@ -326,6 +315,20 @@ int wt_ensemble_create(int64_t n_reactors, int n_zones, int device, const double
     ALLOC(h->q_ctrl, sizeof(int32_t) * wt::Q_WORDS);
     ALLOC(h->q_slots, sizeof(unsigned long long) * (size_t)h->q_cap);
     ALLOC(h->q_next, sizeof(int32_t) * (size_t)h->n_groups);
+    ALLOC(h->q_sticky, sizeof(int32_t));
+    {   // small ensembles (the drop-in's N = 1 above all) are downloaded as one packed image through pinned memory
+        const size_t image = sizeof(double) * (6 * N * nz + 2 * N) + sizeof(uint32_t) * (N + 1);
+        if (image <= WT_SNAPSHOT_PACK_MAX) {
+            h->snap_bytes = (image + 7) & ~(size_t)7;
+            ALLOC(h->snap_dev, h->snap_bytes);
+            if (hipHostMalloc(&h->snap_host, h->snap_bytes, hipHostMallocDefault) != hipSuccess) { cleanup(); return fail(WT_E_HIP, "hipHostMalloc failed"); }
+        }
+        if (hipHostMalloc((void **)&h->err_host, sizeof(int32_t), hipHostMallocDefault) != hipSuccess) { cleanup(); return fail(WT_E_HIP, "hipHostMalloc failed"); }
+        *h->err_host = 0;
+    }
+    if (const char *e = getenv("WT_Q_ITEM")) h->knob_item = atoi(e);
+    if (const char *e = getenv("WT_PLACE_MIN")) h->knob_place_min = atoll(e);
+    if (const char *e = getenv("WT_Q_TICKETS")) h->knob_tickets = atoll(e);
 #undef ALLOC
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { cleanup(); return fail(WT_E_HIP, "hipStreamCreate failed"); }
     h->own_stream = true;
@@ -347,6 +350,7 @@ int wt_ensemble_create(int64_t n_reactors, int n_zones, int device, const double
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemsetAsync(h->q_ctrl, 0, sizeof(int32_t) * wt::Q_WORDS, h->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(h->q_sticky, 0, sizeof(int32_t), h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     if (e != hipSuccess) { cleanup(); return fail(WT_E_HIP, std::string("upload: ") + hipGetErrorString(e)); }
     *out = h;
@@ -360,7 +364,7 @@ int wt_ensemble_destroy(wt_ensemble *h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->trace) (void)hipFree(h->trace);
     void *ptrs[] = {h->par, h->bc, h->pH, h->Cl, h->T, h->time, h->flow, h->dH, h->dRho, h->dK, h->status, h->stats, h->wave_diag,
-                    h->bad_T, h->q_ctrl, h->q_slots, h->q_next, h->perm, h->cost, h->place_hist};
+                    h->bad_T, h->q_ctrl, h->q_slots, h->q_next, h->perm, h->cost, h->place_hist, h->q_sticky, h->snap_dev};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (int s = 0; s < WT_MAX_STREAMS; ++s) {
         if (h->sub_stream[s]) { (void)hipStreamSynchronize(h->sub_stream[s]); (void)hipStreamDestroy(h->sub_stream[s]); }
@@ -370,6 +374,8 @@ int wt_ensemble_destroy(wt_ensemble *h)
                   h->s_ring_head, h->s_ring_cnt, h->s_hist_pos, h->s_out_status, h->s_out_fault, h->s_hist_status,
                   h->s_hist_fault, h->p_ir, h->p_hr, h->p_loop_time, h->p_update_ok, h->diag_out};
     for (void *p : sp) if (p) (void)hipFree(p);
+    if (h->snap_host) (void)hipHostFree(h->snap_host);
+    if (h->err_host) (void)hipHostFree(h->err_host);
     for (hipEvent_t e : h->lt_pool) (void)hipEventDestroy(e);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -437,11 +443,10 @@ int wt_ensemble_step(wt_ensemble *h, double dt, int n_steps, int fused)
         // One launch of q_workers worker wavefronts (more than one only if the call is so long that the queue's
         // 32-bit tickets -- one per work item -- could run out: groups x items per launch stays below 2^30).
         const int W = h->q_workers > 0 ? h->q_workers : 1;
-        const int item = queue_item_steps(n_steps);
+        const int item = queue_item_steps(h, n_steps);
         // Reactors of similar solver cost share a wavefront: once the cost history covers enough outer steps to tell
         // a reactor's regime from a burst, the slots are re-dealt in cost order (three small kernels, no sync).
-        int64_t min_steps = WT_PLACE_MIN_STEPS;
-        if (const char *e = getenv("WT_PLACE_MIN")) if (atoll(e) > 0) min_steps = atoll(e);    // tuning knob (tools/)
+        const int64_t min_steps = h->knob_place_min > 0 ? h->knob_place_min : WT_PLACE_MIN_STEPS;
         auto redeal = [&]() {
             if (h->placement != WT_PLACE_ADAPTIVE || h->cost_steps < min_steps) return;
             const int blocks = (int)((h->N + wtpl::CHUNK - 1) / wtpl::CHUNK);
@@ -449,12 +454,21 @@ int wt_ensemble_step(wt_ensemble *h, double dt, int n_steps, int fused)
             hipLaunchKernelGGL(wtpl::place_count_kernel, dim3(blocks), dim3(wtpl::BINS), 0, h->stream, pa);
             hipLaunchKernelGGL(wtpl::place_scan_kernel, dim3(1), dim3(wtpl::BINS), 0, h->stream, pa, blocks);
             hipLaunchKernelGGL(wtpl::place_scatter_kernel, dim3(blocks), dim3(wtpl::BINS), 0, h->stream, pa);
-            h->cost_steps = 0;
+            h->cost_steps = 0; h->redeals++;
         };
-        int64_t tickets = (int64_t)1 << 30;
-        if (const char *e = getenv("WT_Q_TICKETS")) if (atoll(e) > 0) tickets = atoll(e);     // test knob: force the split
+        const int64_t tickets = h->knob_tickets > 0 ? h->knob_tickets : (int64_t)1 << 30;
         int64_t per_launch = tickets / h->n_groups * item;
         if (per_launch < item) per_launch = item;
+        if (h->n_groups <= W && h->knob_tickets <= 0) {
+            // every group has a worker of its own: nothing to hand over, so no queue -- one plain launch in which
+            // workgroup g advances group g by the whole call (the drop-in's N = 1 lives here: one kernel per step())
+            redeal();
+            const wt::StepArgs a = make_args(h, dt, n_steps, 0, n_steps, chunk);
+            launch_step(h, a, (unsigned)h->n_groups, h->stream);
+            if (h->placement == WT_PLACE_ADAPTIVE) h->cost_steps += n_steps;
+            HIP_TRY(hipGetLastError());
+            return WT_OK;
+        }
         for (int64_t done = 0; done < n_steps; done += per_launch) {
             const int cnt = (int)((n_steps - done < per_launch) ? n_steps - done : per_launch);
             redeal();
@@ -463,6 +477,8 @@ int wt_ensemble_step(wt_ensemble *h, double dt, int n_steps, int fused)
             wt::QueueResetArgs qr{h->q_ctrl, h->q_slots, h->q_next, (int)h->n_groups, h->q_cap};
             hipLaunchKernelGGL(wt::queue_reset_kernel, dim3((unsigned)((h->q_cap + 255) / 256)), dim3(256), 0, h->stream, qr);
             launch_step(h, a, (unsigned)W, h->stream);
+            const wt::QueueCheckArgs qc{h->q_ctrl, h->q_next, (int)h->n_groups, cnt, h->q_sticky};
+            hipLaunchKernelGGL(wt::queue_check_kernel, dim3((unsigned)((h->n_groups + 255) / 256)), dim3(256), 0, h->stream, qc);
             if (h->placement == WT_PLACE_ADAPTIVE) h->cost_steps += cnt;
         }
         HIP_TRY(hipGetLastError());
@@ -559,6 +575,10 @@ int wt_ensemble_sensors_enable(wt_ensemble *h, uint64_t seed, int64_t reactor_ba
         SALLOC(h->s_hist_status, (size_t)history_capacity * wts::NSENS * N);
         SALLOC(h->s_hist_fault, (size_t)history_capacity * wts::NSENS * N);
         SALLOC(h->s_hist_pos, sizeof(int32_t) * N);
+        // slots that are never written (a reactor whose step raised takes no reading) must not hold garbage
+        (void)hipMemsetAsync(h->s_hist_value, 0, sizeof(float) * (size_t)history_capacity * wts::NSENS * N, h->stream);
+        (void)hipMemsetAsync(h->s_hist_status, 0, (size_t)history_capacity * wts::NSENS * N, h->stream);
+        (void)hipMemsetAsync(h->s_hist_fault, 0, (size_t)history_capacity * wts::NSENS * N, h->stream);
     }
 #undef SALLOC
     hipError_t e = hipMemcpy(cfg, cfg_flow, sizeof(double) * N, hipMemcpyHostToDevice);
@@ -718,6 +738,14 @@ int wt_ensemble_get_placement(wt_ensemble *h, int *mode, int32_t *perm)
     return WT_OK;
 }
 
+int wt_ensemble_placement_info(wt_ensemble *h, int64_t *redeals, int64_t *history_steps)
+{
+    if (!h) return fail(WT_E_ARG, "NULL handle");
+    if (redeals) *redeals = h->redeals;
+    if (history_steps) *history_steps = h->cost_steps;
+    return WT_OK;
+}
+
 int wt_ensemble_set_step_limit(wt_ensemble *h, int max_attempts)
 {
     if (!h) return fail(WT_E_ARG, "NULL handle");
@@ -757,7 +785,7 @@ int wt_ensemble_get_schedule(wt_ensemble *h, int *mode, int *n_streams, int *chu
 int wt_ensemble_item_steps(wt_ensemble *h, int n_steps)
 {
     if (!h || n_steps <= 0) return 0;
-    if (h->sched_mode == WT_SCHED_QUEUE) return queue_item_steps(n_steps);
+    if (h->sched_mode == WT_SCHED_QUEUE) return (h->n_groups <= h->q_workers && h->knob_tickets <= 0) ? n_steps : queue_item_steps(h, n_steps);
     const int chunk = h->chunk_steps > 0 ? h->chunk_steps : n_steps;
     return chunk < n_steps ? chunk : n_steps;
 }
@@ -766,10 +794,10 @@ int wt_ensemble_queue_error(wt_ensemble *h, int *error)
 {
     if (!h || !error) return fail(WT_E_ARG, "NULL argument");
     HIP_TRY(hipSetDevice(h->device));
-    int32_t w[wt::Q_WORDS];
-    HIP_TRY(hipMemcpyAsync(w, h->q_ctrl, sizeof w, hipMemcpyDeviceToHost, h->stream));
+    int rc;
+    if ((rc = fetch_sticky(h))) return rc;
     HIP_TRY(hipStreamSynchronize(h->stream));
-    *error = w[wt::Q_ERROR];
+    *error = *h->err_host;      // bit 0: hand-off timed out, bit 1: a group was left behind; sticky until the handle is destroyed
     return WT_OK;
 }
 
@@ -808,11 +836,10 @@ int wt_ensemble_synchronize(wt_ensemble *h)
 {
     if (!h) return fail(WT_E_ARG, "NULL handle");
     HIP_TRY(hipSetDevice(h->device));
+    int rc;
+    if ((rc = fetch_sticky(h))) return rc;
     HIP_TRY(hipStreamSynchronize(h->stream));
-    int qerr = 0;
-    const int rc = wt_ensemble_queue_error(h, &qerr);
-    if (rc != WT_OK) return rc;
-    if (qerr) return fail(WT_E_HIP, "work queue hand-off timed out inside the step kernel; the state is incomplete");
+    if (*h->err_host) return fail(WT_E_HIP, k_incomplete);
     return WT_OK;
 }
 
@@ -823,10 +850,36 @@ static int d2h(wt_ensemble *h, void *dst, const void *src, size_t bytes)
     return WT_OK;
 }
 
+// Small ensembles: pack everything a snapshot can ask for into one device image, one copy into pinned memory, one
+// synchronisation, then scatter into the caller's arrays on the host.  (N = 1: 9 pageable copies of a few dozen
+// bytes each were most of the drop-in's per-step latency.)
+static int packed_snapshot(wt_ensemble *h, double *pH, double *Cl, double *T, double *time, double *flow,
+                           double *H, double *rho, double *kdecay, uint32_t *flags)
+{
+    const int64_t cnt = h->N * h->n;
+    wt::SnapshotArgs a{cnt, h->N, h->pH, h->Cl, h->T, h->dH, h->dRho, h->dK, h->time, h->flow, h->status, h->q_sticky, (double *)h->snap_dev};
+    hipLaunchKernelGGL(wt::snapshot_pack_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, h->stream, a);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(h->snap_host, h->snap_dev, h->snap_bytes, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    const double *img = (const double *)h->snap_host;
+    const size_t b = sizeof(double) * (size_t)cnt, bn = sizeof(double) * (size_t)h->N;
+    double *zone[6] = {pH, Cl, T, H, rho, kdecay};
+    for (int i = 0; i < 6; ++i) if (zone[i]) memcpy(zone[i], img + (size_t)i * cnt, b);
+    const double *tail = img + 6 * (size_t)cnt;
+    if (time) memcpy(time, tail, bn);
+    if (flow) memcpy(flow, tail + h->N, bn);
+    const uint32_t *w = (const uint32_t *)(tail + 2 * h->N);
+    if (flags) memcpy(flags, w, sizeof(uint32_t) * (size_t)h->N);
+    if (w[h->N] != 0) return fail(WT_E_HIP, k_incomplete);
+    return WT_OK;
+}
+
 int wt_ensemble_get_state(wt_ensemble *h, double *pH, double *Cl, double *T, double *time, double *flow)
 {
     if (!h) return fail(WT_E_ARG, "NULL handle");
     HIP_TRY(hipSetDevice(h->device));
+    if (h->snap_host) return packed_snapshot(h, pH, Cl, T, time, flow, nullptr, nullptr, nullptr, nullptr);
     const size_t b = sizeof(double) * (size_t)h->N * h->n;
     int rc;
     if ((rc = d2h(h, pH, h->pH, b))) return rc;
@@ -834,7 +887,9 @@ int wt_ensemble_get_state(wt_ensemble *h, double *pH, double *Cl, double *T, dou
     if ((rc = d2h(h, T, h->T, b))) return rc;
     if ((rc = d2h(h, time, h->time, sizeof(double) * h->N))) return rc;
     if ((rc = d2h(h, flow, h->flow, sizeof(double) * h->N))) return rc;
+    if ((rc = fetch_sticky(h))) return rc;
     HIP_TRY(hipStreamSynchronize(h->stream));
+    if (*h->err_host) return fail(WT_E_HIP, k_incomplete);
     return WT_OK;
 }
 
@@ -843,13 +898,16 @@ int wt_ensemble_get_snapshot(wt_ensemble *h, double *pH, double *Cl, double *T, 
 {
     if (!h) return fail(WT_E_ARG, "NULL handle");
     HIP_TRY(hipSetDevice(h->device));
+    if (h->snap_host) return packed_snapshot(h, pH, Cl, T, time, flow, H, rho, kdecay, flags);
     const size_t b = sizeof(double) * (size_t)h->N * h->n;
     int rc;
     if ((rc = d2h(h, pH, h->pH, b)) || (rc = d2h(h, Cl, h->Cl, b)) || (rc = d2h(h, T, h->T, b))) return rc;
     if ((rc = d2h(h, time, h->time, sizeof(double) * h->N)) || (rc = d2h(h, flow, h->flow, sizeof(double) * h->N))) return rc;
     if ((rc = d2h(h, H, h->dH, b)) || (rc = d2h(h, rho, h->dRho, b)) || (rc = d2h(h, kdecay, h->dK, b))) return rc;
     if ((rc = d2h(h, flags, h->status, sizeof(uint32_t) * h->N))) return rc;
+    if ((rc = fetch_sticky(h))) return rc;
     HIP_TRY(hipStreamSynchronize(h->stream));
+    if (*h->err_host) return fail(WT_E_HIP, k_incomplete);
     return WT_OK;
 }
 
@@ -871,7 +929,10 @@ int wt_ensemble_get_status(wt_ensemble *h, uint32_t *flags)
     if (!h || !flags) return fail(WT_E_ARG, "NULL argument");
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipMemcpyAsync(flags, h->status, sizeof(uint32_t) * h->N, hipMemcpyDeviceToHost, h->stream));
+    int rc;
+    if ((rc = fetch_sticky(h))) return rc;
     HIP_TRY(hipStreamSynchronize(h->stream));
+    if (*h->err_host) return fail(WT_E_HIP, k_incomplete);
     return WT_OK;
 }
 

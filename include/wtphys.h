@@ -117,7 +117,10 @@ int wt_ensemble_get_schedule(wt_ensemble *h, int *mode, int *n_streams, int *chu
 /* outer steps a wavefront-group's state stays in registers before it goes back to memory, for a call of n_steps:
  * the work-item length of the queue schedule (n_steps / 6, at most 32), the launch length of the stream schedule */
 int wt_ensemble_item_steps(wt_ensemble *h, int n_steps);
-/* != 0 after a launch whose work-queue hand-off gave up waiting (never observed; wt_ensemble_synchronize reports it) */
+/* Launch-completeness record, sticky for the life of the handle: bit 0 = a work-queue hand-off gave up waiting, bit 1 =
+ * a launch ended with a wavefront-group short of its step count (checked on the device after every queue launch).
+ * Never observed; while it is non-zero wt_ensemble_synchronize and every state download (get_state / get_snapshot /
+ * get_status) return WT_E_HIP instead of passing an incomplete state off as WT_OK. */
 int wt_ensemble_queue_error(wt_ensemble *h, int *error);
 /* Kept for ABI compatibility, no effect: the reactors sharing a wavefront always start an outer step
  * together (they wait for the slowest of them), which is what makes the end of an outer step a
@@ -135,18 +138,24 @@ int wt_ensemble_set_sync(wt_ensemble *h, int sync_outer);
 #define WT_PLACE_MIN_STEPS 32
 int wt_ensemble_set_placement(wt_ensemble *h, int mode);
 int wt_ensemble_get_placement(wt_ensemble *h, int *mode, int32_t *perm);
+/* how often the slots have been re-dealt so far, and how many outer steps the running cost history covers
+ * (a short run -- fewer than WT_PLACE_MIN_STEPS steps before its timed call -- never re-deals) */
+int wt_ensemble_placement_info(wt_ensemble *h, int64_t *redeals, int64_t *history_steps);
 
 /* Guard the reference lacks.  Where the solution slides along a discontinuity of the RHS (the
  * 8 degC density branch, spatial.py:177-189, under strong heat loss) scipy's Radau takes millions
  * of internal steps for one outer step; the reference would grind through them for hours.  A
  * reactor that needs more than max_attempts step attempts (accepted + rejected) in one outer step
  * is stopped like a solver failure (WT_ST_SOLVER_FAILED | WT_ST_STEP_LIMIT).  Default 2000
- * (a normal step needs 2-4, a hard one a few dozen); 0 = unlimited. */
+ * (a normal step needs 2-4, a hard one a few dozen); 0 = unlimited, as the reference -- an explicit opt-in: the
+ * step kernel cannot be cancelled, and a reactor on that discontinuity then holds its wavefront (and every download)
+ * for as long as the reference would take. */
 int wt_ensemble_set_step_limit(wt_ensemble *h, int max_attempts);
 int wt_ensemble_synchronize(wt_ensemble *h);
 
 /* ReactorState read-back (reactor.py:113-147).  Any pointer may be NULL.
- * pH/Cl/T [N][n]; time, flow [N]. Synchronises the stream. */
+ * pH/Cl/T [N][n]; time, flow [N]. Synchronises the stream.  Ensembles whose whole image fits 256 KiB (the single-reactor
+ * drop-in above all) come back as one packed copy through pinned memory: one kernel, one copy, one synchronisation. */
 int wt_ensemble_get_state(wt_ensemble *h, double *pH, double *Cl, double *T, double *time,
                           double *flow);
 /* everything a ReactorState holds plus the status words, one synchronisation (any pointer may be NULL) */

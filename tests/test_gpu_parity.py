@@ -232,24 +232,25 @@ def test_placement_changes_no_bit(gpu, wt, n):
 
 def test_very_long_calls_are_split_without_a_trace(gpu, wt, monkeypatch):
     """The queue's tickets are 32-bit: a call that would need more than 2^30 of them is cut into several launches
-    (wtphys.hip).  With the ticket budget turned down (WT_Q_TICKETS, test knob) a 23-step call becomes eight launches
-    of one 3-step item per group: state, counters, sensor readings, register images and the commanded boundary equal
-    the single launch's bit for bit."""
+    (wtphys.hip).  With the ticket budget turned down (WT_Q_TICKETS, test knob, read when the ensemble is created) a
+    23-step call becomes eight queue launches of one 3-step item per group: state, counters, sensor readings, register
+    images and the commanded boundary equal, bit for bit, those of the single plain launch that an ensemble with a
+    worker per group gets (88 wavefront-groups here)."""
     N, n, steps = 700, 8, 23
     cols, bc = wt.make_ensemble(N, seed=77)
-    def run():
+    def run(item):
         ens = wt.ReactorEnsemble(cols, n_zones=n); ens.set_boundary(bc)
         ens.set_schedule(0, 5)
         ens.enable_sensors(seed=5); ens.enable_plant_io()
         ens.write_commands(0.1, 0.05, cols["flow_rate"] * 1.1)
-        assert ens.item_steps(steps) == 3
+        assert ens.item_steps(steps) == item
         es = ens.step(1.0, n_steps=steps)
         out = (es.pH, es.chlorine, es.temperature, es.time, es.status, ens.solver_stats(), *ens.sensor_readings(), *ens.input_image(), ens.boundary())
         ens.close()
         return out
-    ref = run()
+    ref = run(steps)
     monkeypatch.setenv("WT_Q_TICKETS", "1")                       # fewer tickets than groups: one item per group and launch
-    got = run()
+    got = run(3)
     for a, b in zip(ref, got):
         assert np.array_equal(a, b, equal_nan=True)
 

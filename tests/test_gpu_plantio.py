@@ -114,3 +114,23 @@ def test_closed_loop_vs_reference_order(gpu, wt):
             ios[r].write_holding("acid_flow_rate", 0.05); ios[r].write_holding("chlorine_flow_rate", float(cmd_cl[r])); ios[r].write_holding("inlet_flow_rate", float(cmd_in[r]))
     assert ens.boundary()[6].max() > 0.1
     ens.close()
+
+
+def test_set_boundary_wins_over_earlier_commands(gpu, wt):
+    """With plant I/O on, every PLC scan rewrites boundary rows 0 / 4 / 6 on the device; a later ``set_boundary`` with
+    the very block the host sent before must still be uploaded (the host's copy is no longer what the device holds)."""
+    cols, bc = wt.make_ensemble(64)
+    ens = wt.ReactorEnsemble(cols, n_zones=4)
+    ens.set_boundary(bc)
+    ens.enable_sensors(seed=5); ens.enable_plant_io()
+    ens.write_commands(1.5, 0.75, 9.0)
+    ens.step(1.0, n_steps=3)
+    assert np.allclose(ens.boundary()[[4, 6, 0]], np.array([[1.5], [0.75], [9.0]]))
+    for _ in range(2):                       # the first and every later identical call restore the host's rows
+        ens.write_commands(0.0, 0.0, 0.0)    # (0 inlet command = "leave the inlet alone", so nothing overrides it again)
+        ens.set_boundary(bc)
+        assert np.array_equal(ens.boundary(), bc)
+        ens.write_commands(1.5, 0.75, 9.0)
+        ens.step(1.0, n_steps=2)
+        assert np.allclose(ens.boundary()[[4, 6, 0]], np.array([[1.5], [0.75], [9.0]]))
+    ens.close()

@@ -122,3 +122,23 @@ def test_suite_at_config5_share_vs_oracle(gpu, wt, N, n):
     v, s, f = ens.sensor_readings()
     assert np.array_equal(v[:, sample], hv[-1], equal_nan=True)
     ens.close()
+
+
+def test_history_counts_only_the_reads_taken(gpu, wt):
+    """A reactor whose step raises takes no reading from then on (the reference's loop stops at the raise): its history
+    length is the number of completed steps, what lies beyond is zero, not uninitialised memory; its neighbour in the
+    same ensemble keeps reading.  (Cold-run fixture g4: the reference raises at step index 34.)"""
+    from conftest import golden_json
+    g = golden_json("g4_faults.json")["cold_run"]
+    cfg = wt.ReactorConfiguration(**g["config"])
+    b = wt.BoundaryConditions(**dict(zip(wt.params.BOUNDARY_FIELDS, g["bc"])))
+    ens = wt.ReactorEnsemble([cfg, wt.ReactorConfiguration(n_zones=cfg.n_zones)])
+    ens.set_boundary([b, wt.BoundaryConditions()])
+    ens.enable_sensors(seed=3, history=64)
+    for k in (10, 30, 20):
+        ens.step(1.0, n_steps=k)
+    v, st, fl, n = ens.sensor_history()
+    assert n[0] == g["raise_step_index"] and n[1] == 60
+    assert not v[n[0]:, :, 0].any() and not st[n[0]:, :, 0].any() and not fl[n[0]:, :, 0].any()
+    assert st[:n[1], :, 1].any()                      # the neighbour's sixty reads are there (status codes of warming-up sensors)
+    ens.close()

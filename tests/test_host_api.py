@@ -235,3 +235,20 @@ def test_host_modules_are_not_transliterations():
         lines = oc.normalised_lines(os.path.join(ROOT, "ics-wt-physicsengine_amd", "core", name))
         share = sum(l in known for l in lines) / len(lines)
         assert share < 0.25, (name, share)
+
+
+def test_build_staleness_list_matches_the_includes():
+    """``_native.build`` rebuilds when any source is newer than the library: the list must be wtphys.hip plus exactly
+    the local headers it (transitively) includes -- no stale names, nothing missing."""
+    import importlib
+    native = importlib.import_module("ics-wt-physicsengine_amd.core._native")
+    seen, todo = set(), ["wtphys.hip"]
+    while todo:
+        f = todo.pop()
+        if f in seen:
+            continue
+        seen.add(f)
+        text = open(os.path.join(native.CSRC, f)).read()
+        todo += [m for m in re.findall(r'#include "([^"/]+)"', text) if os.path.exists(os.path.join(native.CSRC, m))]
+    assert seen == set(native.BUILD_SOURCES)
+    assert not [f for f in os.listdir(native.CSRC) if f.endswith((".hpp", ".hip")) and f not in seen], "dead source in csrc/"
