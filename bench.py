@@ -39,7 +39,7 @@ sys.path.insert(0, ROOT)
 DEFAULT_CHUNK = 50            # outer steps per work item (the library's default schedule, WT_DEFAULT_CHUNK)
 HBM_PEAK_GBS = 8000.0         # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 FP64_VECTOR_PEAK_TFLOPS = 78.6  # 256 CUs x 4 SIMDs x 16 fp64 FMA lanes/clk x 2 flop x 2.4 GHz
-PROFILE_DIR = os.path.join(ROOT, "profiles", "r2")
+PROFILE_DIR = os.path.join(ROOT, "profiles", "r3")
 # BASELINE.md section 2 (survey container, 1 core of an 8-core Xeon @ 2.1 GHz): the reference cannot
 # travel to the GPU box, so its measured rate is carried as a labelled constant
 REFERENCE_PYTHON = {"value": 1.63e3, "unit": "reactor-zone-steps/s", "cores": 1,
@@ -343,8 +343,12 @@ def run_rank(args) -> int:
             zs_per_launch = N * n * args.steps / max(n_launch, 1)
             bytes_per_launch = per_unit * zs_per_launch
             achieved = bytes_per_launch / avg_launch_s * in_flight / 1e9       # == rank-0 bytes / region time
-            tr = _profile_json("traffic.json")          # rocprofv3 PMC passes (tools/collect_r2_pmc.sh)
-            traffic = tr["hbm_bytes_per_zone_step"] * zs_per_launch if tr else None
+            # measured HBM traffic: rocprofv3 PMC passes (tools/collect_r3.sh), one entry per profiled work-item length --
+            # how often a group's state returns to memory depends on it, so a figure is only quoted for a run of the
+            # same zone count and item length as the profiled one, never scaled from another
+            tr = _profile_json("traffic.json")
+            entry = (tr or {}).get("by_steps_per_item", {}).get(str(item_steps)) if tr and tr.get("zones") == n else None
+            traffic = entry["hbm_bytes_per_zone_step"] * zs_per_launch if entry else None
             fl = _profile_json("pmc_fp64.json")
             compute = None
             if fl and n == fl.get("zones"):
@@ -353,7 +357,7 @@ def run_rank(args) -> int:
                 compute = {"bound": "fp64 vector ALU", "achieved": ach, "peak": FP64_VECTOR_PEAK_TFLOPS * world,
                            "unit": "TFLOP/s", "frac": ach / (FP64_VECTOR_PEAK_TFLOPS * world),
                            "fp64_flop_per_zone_step": fpz,
-                           "source": "profiles/r2/pmc_fp64.json: (SQ_INSTS_VALU_ADD_F64 + MUL_F64 + 2 FMA_F64 + TRANS_F64) "
+                           "source": "profiles/r3/pmc_fp64.json: (SQ_INSTS_VALU_ADD_F64 + MUL_F64 + 2 FMA_F64 + TRANS_F64) "
                                      "x 64 lanes / zone-steps of the profiled run; peak = 1024 SIMDs x 16 FMA lanes x 2 x 2.4 GHz"}
             out["roofline"] = {
                 "bound": "hbm",
@@ -362,8 +366,8 @@ def run_rank(args) -> int:
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
-                "traffic_source": ("profiles/r2/traffic.json: rocprofv3 (2 x FETCH_SIZE + WRITE_SIZE) per zone-step of the "
-                                   "profiled run x zone-steps per launch") if tr else None,
+                "traffic_source": (f"profiles/r3/traffic.json[steps_per_item={item_steps}]: rocprofv3 (2 x FETCH_SIZE + WRITE_SIZE) per "
+                                   f"zone-step of the profiled run ({entry['workload']}) x zone-steps per launch") if entry else None,
                 "kernel": sched.get("kernel", "wt::step_kernel"),
                 "avg_launch_us": avg_launch_s * 1e6,
                 "max_launch_us": launch_max_ms * 1e3,

@@ -79,3 +79,24 @@ def test_roofline_bytes_formula():
     assert bench.algorithmic_bytes_per_zone_step(8, 1) == pytest.approx(48 + 24 + 10)
     assert bench.algorithmic_bytes_per_zone_step(8, 50) == pytest.approx(48 + 34 / 50)
     assert bench.algorithmic_bytes_per_zone_step(4, 5) == pytest.approx(48 + 44 / 5)
+
+
+@pytest.mark.parametrize("sensors", [False, True], ids=["config4", "config5"])
+def test_eight_rank_rehearsal_of_the_baseline_configs(wt, sensors):
+    """BASELINE configs 4 and 5 exactly as the driver will launch them on a node -- 100 000 reactors x 8 zones cut over
+    8 ranks (12 500 each), with and without the sensor suite -- rehearsed on the CPU over gloo: launcher, sharding,
+    MAX-reduced timing, the padded all_gather and the single JSON line.  (No stepping: there is no GPU here.)"""
+    args = ["--gpus", "8", "--total-reactors", "100000", "--steps", "2", "--warmup", "1", "--dry-run"] + (["--sensors"] if sensors else [])
+    p = _run(args, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = _json_lines(p.stdout)
+    assert len(lines) == 1, p.stdout
+    o = lines[0]
+    assert o["n_gpus"] == 8 and o["scaling"] == "strong" and o["dry_run"] is True
+    assert o["shard_sizes"] == [12500] * 8
+    assert o["config"]["reactors_total"] == 100000 and o["config"]["reactors_per_gpu"] == 12500 and o["config"]["zones"] == 8
+    assert o["final_gather_ms"] is not None and o["final_gather_ms"] >= 0
+    assert "8" in o["config"]["sharding"]
+    cols, _ = wt.make_ensemble(100000)
+    expect = 8 * float(cols["initial_pH"].sum() + cols["initial_chlorine"].sum() + cols["temperature"].sum())
+    assert abs(o["state_checksum"] - expect) <= 1e-9 * abs(expect)     # the gathered block is the whole ensemble, in order

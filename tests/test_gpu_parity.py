@@ -668,3 +668,23 @@ def test_dropin_surface_and_reference_validators(gpu, wt, capsys):
         assert line in out, line
     wt.run_all_validations()
     assert "ALL VALIDATIONS PASSED" in capsys.readouterr().out
+
+
+def test_bench_as_the_driver_launches_one_rank(gpu):
+    """bench.py under the driver's environment for one rank of config 4's shape (RANK / WORLD_SIZE set as
+    torch.distributed.run sets them, 12 500 reactors x 8 zones, --steps 20 --warmup 5): RCCL initialisation, the timed
+    loop, the device-to-device export and the final all_gather run through the bench's own code path on hardware."""
+    import json, os, socket, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--total-reactors", "12500", "--steps", "20",
+                        "--warmup", "5", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    o = lines[0]
+    assert o["n_gpus"] == 1 and o["steps"] == 20 and o["warmup"] == 5 and o["scaling"] == "strong"
+    assert o["config"]["reactors_total"] == 12500 and o["flagged_reactors"] == 0
+    assert o["final_gather_ms"] is not None and o["value"] > 1e8
+    assert o["roofline"]["bound"] == "hbm" and 0 < o["roofline"]["frac"] < 1
