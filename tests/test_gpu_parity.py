@@ -142,7 +142,7 @@ def test_full_size_ensemble_vs_oracle(gpu, wt, oracle, n, N):
     # algorithm drift apart by up to 3e-6 there), so the bound is asserted on all but 1e-5 of the
     # samples and the solver's own tolerance bounds the rest.
     assert np.mean(err < TOL) > 1 - 1e-5
-    assert err.max() < 2e-5
+    assert err.max() < 1e-5
     # report-style tight bound: all but a handful of (reactor, zone) samples agree to 1e-9
     assert np.mean(err < 1e-9) > 0.999
     assert np.allclose(es.time[ok], steps * 1.0)
@@ -552,6 +552,33 @@ def test_nonfinite_state_is_contained(gpu, wt, oracle):
         assert r.state.time == nf["nan"]["time_after"] and np.array_equal(r.state.pH, [7.0, bad, 7.0, 7.0], equal_nan=True)
 
 
+@pytest.mark.parametrize("n", [8, 20])
+def test_full_size_hundred_steps_vs_oracle(gpu, wt, oracle, n):
+    """BASELINE configs 2/3 at full size over 100 outer steps (ten checkpoints): every reactor and zone against the
+    oracle -- the distribution tools/parity_report.py publishes (profiles/r3/parity_report.json), asserted here so that
+    the driver's run sees it.  Observed: 99.99992 % (n = 8) / 99.9996 % (n = 20) of 2.4 M / 6 M samples within 1e-6,
+    p99.99 5.6e-9 / 1.1e-7, max 2.2e-6 / 4.7e-6; the samples beyond 1e-6 belong to the reactors pinned against the
+    reference itself in test_outlier_reactors_vs_reference."""
+    N, steps, every = 10000, 100, 10
+    cols, bc = wt.make_ensemble(N)
+    ens = wt.ReactorEnsemble(cols, n_zones=n); ens.set_boundary(bc)
+    s0 = ens.state
+    pH, Cl, T, t = s0.pH, s0.chlorine, s0.temperature, s0.time
+    errs = []
+    for k in range(steps // every):
+        es = ens.step(1.0, n_steps=every)
+        pH, Cl, T, t, ost = oracle.ensemble_step(n, ens.constants, bc, 1.0, every, pH, Cl, T, t, nthreads=16)
+        assert not es.status.any() and not ost.any()
+        errs.append(np.stack([np.abs(es.pH - pH) / np.abs(pH), np.abs(es.chlorine - Cl) / np.abs(Cl),
+                              np.abs(es.temperature - T) / np.abs(T)]).reshape(-1))
+    ens.close()
+    err = np.concatenate(errs)
+    assert np.mean(err <= TOL) >= 1 - 1e-5                       # north-star tolerance on all but 1e-5 of the samples
+    assert np.mean(err <= 1e-9) >= 0.995
+    assert np.percentile(err, 99.99) <= 5e-7
+    assert err.max() < 1e-5                                      # everything within the solver's own tolerance
+
+
 # ---------------------------------------------------------------- pins against the reference itself (g10, g11)
 @pytest.mark.parametrize("n", [4, 8, 20])
 def test_outlier_reactors_vs_reference(gpu, wt, oracle, n):
@@ -579,10 +606,13 @@ def test_outlier_reactors_vs_reference(gpu, wt, oracle, n):
         same_counters += int(np.count_nonzero(np.all(ens.solver_stats()[:, :4] == g["stats"][:, (k + 1) * every - 1, :4], axis=1)))
     ens.close()
     e_orc = np.maximum(outlier_errors(wt, oracle, n, 0), outlier_errors(wt, oracle, n, 1))
-    assert e_gpu.max() < 2e-5                                               # the solver's own tolerance
-    assert e_gpu.max() <= max(3.0 * e_orc.max(), 1e-6)                      # no worse than oracle vs reference
-    assert (e_gpu > 1e-6).sum() <= (e_orc > 1e-6).sum() + max(2, S // 4)
-    assert same_counters > 0.5 * S * (steps // every)                       # mostly the reference's own decision sequence
+    # observed (profiles/r3/parity_report.json, outlier_reactors_vs_reference): GPU max 3.4e-7 / 1.6e-6 / 5.4e-6 for
+    # n = 4 / 8 / 20 against the oracle's 7.7e-9 / 1.4e-6 / 4.0e-6; 0 / 1 / 8 reactors beyond 1e-6 against 0 / 1 / 10;
+    # the reference's own decision counters at 30/30, 80/80, 475/480 checkpoints
+    assert e_gpu.max() < 1e-5                                               # the solver's own tolerance
+    assert e_gpu.max() <= max(1.5 * e_orc.max(), 1e-6)                      # no worse than oracle vs reference
+    assert (e_gpu > 1e-6).sum() <= (e_orc > 1e-6).sum() + 2
+    assert same_counters >= 0.95 * S * (steps // every)                     # the reference's own decision sequence
 
 
 def _branch(wt, name):

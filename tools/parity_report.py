@@ -1,5 +1,6 @@
 """Parity report: HIP path vs the reference's golden trajectories and vs the CPU oracle on
-the full-size bench ensembles.  Writes profiles/r2/parity_report.json (run on the GPU box)."""
+the full-size bench ensembles, and vs the reference itself on the reactors where those two differ most (g10).
+Writes gpurun_out/parity_report.json (run on the GPU box; copied to profiles/r3/)."""
 import glob, importlib, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -60,6 +61,33 @@ for n in (4, 8, 20):
         "fraction_within_1e-6": float(np.mean(allerr <= 1e-6)), "fraction_within_1e-9": float(np.mean(allerr <= 1e-9)),
         **pct(allerr)}
     ens.close()
+
+# 3. the outlier reactors of the bench ensembles (GPU vs oracle > 1e-7) against 100 steps of the Python reference
+#    itself (tests/golden/g10_outliers_n*.npz), with the oracle's own distance to the reference beside it
+from test_oracle_golden import outlier_errors
+out["outlier_reactors_vs_reference"] = {}
+for n in (4, 8, 20):
+    g = np.load(os.path.join(ROOT, "tests", "golden", f"g10_outliers_n{n}.npz"))
+    R, every, steps = g["reactors"], int(g["every"]), int(g["steps"])
+    cols, bc = wt.make_ensemble(int(R.max()) + 1)
+    ens = wt.ReactorEnsemble({k: v[R] for k, v in cols.items()}, n_zones=n)
+    ens.set_boundary(np.ascontiguousarray(bc[:, R]))
+    S = len(R); e_gpu = np.zeros(S); same = 0
+    for k in range(steps // every):
+        es = ens.step(1.0, n_steps=every)
+        snap = g["snaps"][:, k]
+        got = np.stack([es.pH, es.chlorine, es.temperature], axis=1)
+        e_gpu = np.maximum(e_gpu, np.max(np.abs(got - snap) / np.abs(snap), axis=(1, 2)))
+        same += int(np.count_nonzero(np.all(ens.solver_stats()[:, :4] == g["stats"][:, (k + 1) * every - 1, :4], axis=1)))
+    ens.close()
+    e_lu, e_tri = outlier_errors(wt, O, n, 0), outlier_errors(wt, O, n, 1)
+    out["outlier_reactors_vs_reference"][f"n{n}"] = {
+        "reactors": int(S), "steps": steps, "compared_every": every,
+        "gpu_max_rel_err": float(e_gpu.max()), "gpu_reactors_beyond_1e-6": int((e_gpu > 1e-6).sum()),
+        "gpu_checkpoints_with_reference_counters": same, "checkpoints": int(S * (steps // every)),
+        "oracle_dense_lu_max_rel_err": float(e_lu.max()), "oracle_dense_lu_reactors_beyond_1e-6": int((e_lu > 1e-6).sum()),
+        "oracle_tridiagonal_max_rel_err": float(e_tri.max()), "oracle_tridiagonal_reactors_beyond_1e-6": int((e_tri > 1e-6).sum())}
+print(json.dumps(out["outlier_reactors_vs_reference"], indent=1))
 
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 with open(os.path.join(ROOT, "gpurun_out", "parity_report.json"), "w") as f:
