@@ -301,6 +301,7 @@ struct Lane {
     // 64-bit lane mask for the whole solver loop
     uint32_t m_lo[7], m_hi[7];
     int a_lo[7], a_hi[7];     // ds_bpermute byte addresses of lane -/+ 2^l (segments that straddle DPP rows)
+    int a_pt; uint32_t m_pt;  // the one partner of the top cyclic-reduction level (from_partner), and whether it exists
     int base;                 // lane id of zone 0 of this segment
     unsigned long long segmask;
     Divisor d3n, d9n;         // 3n, 9n: component counts of the RMS norms (common.py:63-65, radau.py:105)
@@ -332,13 +333,6 @@ template <bool ROW, int S> __device__ __forceinline__ double from_lo(const Lane 
     else if constexpr (S == 1) return dpp_mov<0x138>(x);  // wave_shr:1
     else return bpermute(L.a_lo[ilog2(S)], x);
 }
-template <bool ROW, int S> __device__ __forceinline__ double from_hi(const Lane &L, double x)
-{   // value held by lane (this + S)
-    if constexpr (ROW && S < 16) return dpp_mov<0x100 + S>(x);      // row_shl:S
-    else if constexpr (S == 1) return dpp_mov<0x130>(x);  // wave_shl:1
-    else return bpermute(L.a_hi[ilog2(S)], x);
-}
-
 // A value read from outside the segment only ever meets a zero coefficient, so it is
 // enough to make it FINITE: clearing the high dword (sign, exponent, top mantissa bits)
 // turns any NaN/Inf another reactor may hold into a denormal.  One v_and per read (with the
@@ -346,6 +340,31 @@ template <bool ROW, int S> __device__ __forceinline__ double from_hi(const Lane 
 __device__ __forceinline__ double keep_m(uint32_t mask, double x)
 {
     return __hiloint2double(__double2hiint(x) & (int)mask, __double2loint(x));
+}
+
+// At the top level of the cyclic reduction (stride S = 2^(LV-1) >= n/2) a zone has at most ONE partner: zone z - S if
+// z >= S, else zone z + S if that exists.  ROW kernels (n = 2 S): partner = z xor S, a quad permutation (n = 2, 4), a
+// row rotation (n = 16) or two bank-masked row shifts into one register (n = 8).  Otherwise one ds_bpermute.
+template <int CTRL, int BANKS> __device__ __forceinline__ double dpp_merge(double old, double x)
+{
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(x), CTRL, 0xf, BANKS, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(x), CTRL, 0xf, BANKS, false);
+    return __hiloint2double(hi, lo);
+}
+template <bool ROW, int S> __device__ __forceinline__ double from_partner(const Lane &L, double x)
+{
+    if constexpr (ROW && S == 1) return dpp_mov<0xB1>(x);            // quad_perm [1,0,3,2]
+    else if constexpr (ROW && S == 2) return dpp_mov<0x4E>(x);       // quad_perm [2,3,0,1]
+    else if constexpr (ROW && S == 4) return dpp_merge<0x104, 0x5>(dpp_merge<0x114, 0xA>(x, x), x);   // row_shr:4 -> zones 4..7, row_shl:4 -> zones 0..3
+    else if constexpr (ROW && S == 8) return dpp_mov<0x128>(x);      // row_ror:8
+    else return keep_m(L.m_pt, bpermute(L.a_pt, x));
+}
+
+template <bool ROW, int S> __device__ __forceinline__ double from_hi(const Lane &L, double x)
+{   // value held by lane (this + S)
+    if constexpr (ROW && S < 16) return dpp_mov<0x100 + S>(x);      // row_shl:S
+    else if constexpr (S == 1) return dpp_mov<0x130>(x);  // wave_shl:1
+    else return bpermute(L.a_hi[ilog2(S)], x);
 }
 
 __device__ __forceinline__ bool seg_any(const Lane &L, bool p) { return (__ballot(p) & L.segmask) != 0ull; }
@@ -741,10 +760,10 @@ struct Jac {
 // (three at n > 32): the first NREG slots (real-shift factors) stay in registers instead.  All of them in LDS
 // means three wavefronts per CU at n = 20 and 0.6x the throughput (measured); all real-shift factors in registers
 // costs scratch spills -- so exactly as many as do not fit (n <= 32).
-constexpr int fstore_total_slots(int LV) { return 3 * (2 * LV + 1) + 3 * (4 * LV + 2); }
+constexpr int fstore_total_slots(int LV) { return 3 * (2 * LV) + 3 * (4 * LV); }
 constexpr int fstore_lds_slots(int LV)
 {
-    if (LV >= 6) return fstore_total_slots(LV) - 3 * (2 * LV + 1);                    // n > 32: three wavefronts per CU either way; registers measured faster
+    if (LV >= 6) return fstore_total_slots(LV) - 3 * (2 * LV);                        // n > 32: three wavefronts per CU either way; registers measured faster
     const int budget = 40960;                                                         // bytes per wavefront at four per CU
     const int fixed = (RK_UNI * rk_maxr(LV) + RK_LANE * 64 + RK_MAXR) * 8;            // LdsMap: reactor constants, history base, reactor indices
     const int fit = (budget - fixed) / 512;
@@ -758,10 +777,11 @@ template <int LV> struct FStore {
     __device__ __forceinline__ double ld(int slot) const { return (slot < NREG) ? reg[slot < NREG ? slot : 0] : base[(slot - NREG) * 64]; }
     __device__ __forceinline__ void st(int slot, double v) { if (slot < NREG) reg[slot < NREG ? slot : 0] = v; else base[(slot - NREG) * 64] = v; }
 };
-// slot map: real system k (0..2): [k*(2LV+1) + 2l] = alpha_l, [+2l+1] = gamma_l, [+2LV] = 1/d
-//           complex system k:      CB + k*(4LV+2) + 4l + {0,1,2,3} = al.r, al.i, ga.r, ga.i; [+4LV, +4LV+1] = 1/d
+// slot map: real system k (0..2): [k RS + 2l] = alpha_l, [+2l+1] = gamma_l for the levels l < LV-1 below the top one,
+//           [+2(LV-1)] = the top level's one factor (alpha for zones >= 2^(LV-1), gamma below: never both), [+2LV-1] = 1/d
+//           complex system k: CB + k CS + 4l + {0,1,2,3} = al.r, al.i, ga.r, ga.i; [+4(LV-1), +1] = top factor, [+2, +3] = 1/d
 template <int LV> struct FSlots {
-    static constexpr int RS = 2 * LV + 1, CS = 4 * LV + 2, CB = 3 * RS, TOTAL = 3 * RS + 3 * CS;
+    static constexpr int RS = 2 * LV, CS = 4 * LV, CB = 3 * RS, TOTAL = 3 * RS + 3 * CS;
     static constexpr int LDS_SLOTS = TOTAL - FStore<LV>::NREG;
 };
 
@@ -826,7 +846,39 @@ __device__ __forceinline__ void pcr_factor_level_all(const Lane &L, double ar[3]
         const int c0 = S::CB + k * S::CS + 4 * l;
         F.st(c0, al.r); F.st(c0 + 1, al.i); F.st(c0 + 2, ga.r); F.st(c0 + 3, ga.i);
     }
-    if constexpr (l + 1 < LV) pcr_factor_level_all<ROW, LV, l + 1>(L, ar, dr, cr, ac, dc, cc, F);
+    if constexpr (l + 2 < LV) pcr_factor_level_all<ROW, LV, l + 1>(L, ar, dr, cr, ac, dc, cc, F);
+}
+
+// The top level (stride 2^(LV-1) >= n/2): a zone couples to its one partner only -- `a` is zero below the stride, `c`
+// at and above it, so a + c is whichever is there (exactly), and the partner's a + c the coefficient that couples
+// back.  One factor and a third of the cross-lane moves of a regular level; the same bits.
+template <bool ROW, int LV>
+__device__ __forceinline__ void pcr_factor_top_all(const Lane &L, double ar[3], double dr[3], double cr[3],
+                                                   cplx ac[3], cplx dc[3], cplx cc[3], FStore<LV> &F)
+{
+    using S = FSlots<LV>;
+    constexpr int s = 1 << (LV - 1);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const double id = rcp(dr[k]), w = ar[k] + cr[k];
+        const double p_id = from_partner<ROW, s>(L, id), p_w = from_partner<ROW, s>(L, w);
+        const double f = w * p_id;
+        dr[k] = dr[k] - f * p_w;
+        F.st(k * S::RS + 2 * (LV - 1), f);
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const cplx cid = cinv(dc[k]), w = {ac[k].r + cc[k].r, ac[k].i + cc[k].i};
+        const cplx p_id = {from_partner<ROW, s>(L, cid.r), from_partner<ROW, s>(L, cid.i)};
+        const cplx p_w = {from_partner<ROW, s>(L, w.r), from_partner<ROW, s>(L, w.i)};
+        const cplx f = cmul(w, p_id);
+        double dre = dc[k].r, dim = dc[k].i;
+        dre = __builtin_fma(-f.r, p_w.r, dre); dim = __builtin_fma(-f.r, p_w.i, dim);
+        dre = __builtin_fma(f.i, p_w.i, dre);  dim = __builtin_fma(-f.i, p_w.r, dim);
+        dc[k] = {dre, dim};
+        const int c0 = S::CB + k * S::CS + 4 * (LV - 1);
+        F.st(c0, f.r); F.st(c0 + 1, f.i);
+    }
 }
 
 // The six factored systems of one (h, J) pair: scipy's LU_real / LU_complex.
@@ -843,48 +895,59 @@ __device__ __forceinline__ void factorize(const Lane &L, const Jac &J, double h,
     cplx ac[3] = {{ar[0], 0.0}, {ar[1], 0.0}, {ar[2], 0.0}};
     cplx dc[3] = {{mcr - J.tt[1], mci}, {mcr - J.pp[1], mci}, {mcr - J.cc[1], mci}};
     cplx cc[3] = {{cr[0], 0.0}, {cr[1], 0.0}, {cr[2], 0.0}};
-    pcr_factor_level_all<ROW, LV, 0>(L, ar, dr, cr, ac, dc, cc, F);
+    if constexpr (LV > 1) pcr_factor_level_all<ROW, LV, 0>(L, ar, dr, cr, ac, dc, cc, F);
+    pcr_factor_top_all<ROW, LV>(L, ar, dr, cr, ac, dc, cc, F);
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        F.st(k * S::RS + 2 * LV, rcp(dr[k]));
+        F.st(k * S::RS + 2 * LV - 1, rcp(dr[k]));
         const cplx inv = cinv(dc[k]);
-        F.st(S::CB + k * S::CS + 4 * LV, inv.r); F.st(S::CB + k * S::CS + 4 * LV + 1, inv.i);
+        F.st(S::CB + k * S::CS + 4 * LV - 2, inv.r); F.st(S::CB + k * S::CS + 4 * LV - 1, inv.i);
     }
 }
 
 // x = (mu_real/h I - J)^-1 b, in place, b indexed by species.  The factors of all three systems are
 // fetched from LDS in one batch up front (one exposed LDS round trip instead of one per level).
-template <int LV> struct RealFactors { double a[LV], g[LV], inv; };
+template <int LV> struct RealFactors { double a[LV > 1 ? LV - 1 : 1], g[LV > 1 ? LV - 1 : 1], f, inv; };
+
+template <int LV>
+__device__ __forceinline__ void load_real(const FStore<LV> &F, int k, RealFactors<LV> &s)
+{
+    using S = FSlots<LV>;
+#pragma unroll
+    for (int l = 0; l + 1 < LV; ++l) { s.a[l] = F.ld(k * S::RS + 2 * l); s.g[l] = F.ld(k * S::RS + 2 * l + 1); }
+    s.f = F.ld(k * S::RS + 2 * (LV - 1)); s.inv = F.ld(k * S::RS + 2 * LV - 1);
+}
 
 template <bool ROW, int LV, int l>
 __device__ __forceinline__ void pcr_real_level(const Lane &L, const RealFactors<LV> &s, double &b)
 {
-    constexpr int st = 1 << l;
-    const double b_lo = from_lo<ROW, st>(L, b), b_hi = from_hi<ROW, st>(L, b);
-    b = b - s.a[l] * keep_m(L.m_lo[l], b_lo) - s.g[l] * keep_m(L.m_hi[l], b_hi);
-    if constexpr (l + 1 < LV) pcr_real_level<ROW, LV, l + 1>(L, s, b);
+    if constexpr (l + 1 < LV) {
+        constexpr int st = 1 << l;
+        const double b_lo = from_lo<ROW, st>(L, b), b_hi = from_hi<ROW, st>(L, b);
+        b = b - s.a[l] * keep_m(L.m_lo[l], b_lo) - s.g[l] * keep_m(L.m_hi[l], b_hi);
+        pcr_real_level<ROW, LV, l + 1>(L, s, b);
+    } else {
+        b = b - s.f * from_partner<ROW, (1 << (LV - 1))>(L, b);     // top level: one partner
+    }
 }
 
 template <bool ROW, int LV>
 __device__ __forceinline__ void solve_real(const Lane &L, const Jac &J, const FStore<LV> &F, double b[3])
 {
-    using S = FSlots<LV>;
+    // (many levels: a system's factors are fetched when its turn comes, or the three sets together crowd the register file)
     RealFactors<LV> fT, fP, fC;
-#pragma unroll
-    for (int l = 0; l < LV; ++l) {
-        fT.a[l] = F.ld(0 * S::RS + 2 * l); fT.g[l] = F.ld(0 * S::RS + 2 * l + 1);
-        fP.a[l] = F.ld(1 * S::RS + 2 * l); fP.g[l] = F.ld(1 * S::RS + 2 * l + 1);
-        fC.a[l] = F.ld(2 * S::RS + 2 * l); fC.g[l] = F.ld(2 * S::RS + 2 * l + 1);
-    }
-    fT.inv = F.ld(0 * S::RS + 2 * LV); fP.inv = F.ld(1 * S::RS + 2 * LV); fC.inv = F.ld(2 * S::RS + 2 * LV);
+    load_real<LV>(F, 0, fT);
+    if constexpr (LV < 4) { load_real<LV>(F, 1, fP); load_real<LV>(F, 2, fC); }
     double xT = b[STT];
     pcr_real_level<ROW, LV, 0>(L, fT, xT);
     xT *= fT.inv;
+    if constexpr (LV >= 4) load_real<LV>(F, 1, fP);
     const double xT_lo_r = from_lo<ROW, 1>(L, xT), xT_hi_r = from_hi<ROW, 1>(L, xT);
     const double xT_lo = keep_m(L.m_lo[0], xT_lo_r), xT_hi = keep_m(L.m_hi[0], xT_hi_r); // J.pt/ct[0,2] are 0 there
     double xP = b[SPH] + (J.pt[0] * xT_lo + J.pt[1] * xT + J.pt[2] * xT_hi);
     pcr_real_level<ROW, LV, 0>(L, fP, xP);
     xP *= fP.inv;
+    if constexpr (LV >= 4) load_real<LV>(F, 2, fC);
     double xC = b[SCL] + (J.ct[0] * xT_lo + J.ct[1] * xT + J.ct[2] * xT_hi) + J.cp * xP;
     pcr_real_level<ROW, LV, 0>(L, fC, xC);
     xC *= fC.inv;
@@ -895,7 +958,10 @@ __device__ __forceinline__ void solve_real(const Lane &L, const Jac &J, const FS
 // cyclic-reduction chains are independent, so interleaving them doubles the instruction-level
 // parallelism of what is otherwise one long dependent chain, and each system's factors are
 // fetched from LDS in one batch (one wait per system instead of one per level).
-template <int LV> struct SysFactors { double ra[LV], rg[LV], rinv; cplx ca[LV], cg[LV], cinv; };
+template <int LV> struct SysFactors {
+    static constexpr int NL = LV > 1 ? LV - 1 : 1;
+    double ra[NL], rg[NL], rf, rinv; cplx ca[NL], cg[NL], cf, cinv;
+};
 
 template <int LV>
 __device__ __forceinline__ void load_sys(const FStore<LV> &F, int k, SysFactors<LV> &s)
@@ -903,31 +969,44 @@ __device__ __forceinline__ void load_sys(const FStore<LV> &F, int k, SysFactors<
     using S = FSlots<LV>;
     const int r0 = k * S::RS, c0 = S::CB + k * S::CS;
 #pragma unroll
-    for (int l = 0; l < LV; ++l) {
+    for (int l = 0; l + 1 < LV; ++l) {
         s.ra[l] = F.ld(r0 + 2 * l); s.rg[l] = F.ld(r0 + 2 * l + 1);
         s.ca[l] = {F.ld(c0 + 4 * l), F.ld(c0 + 4 * l + 1)};
         s.cg[l] = {F.ld(c0 + 4 * l + 2), F.ld(c0 + 4 * l + 3)};
     }
-    s.rinv = F.ld(r0 + 2 * LV);
-    s.cinv = {F.ld(c0 + 4 * LV), F.ld(c0 + 4 * LV + 1)};
+    s.rf = F.ld(r0 + 2 * (LV - 1)); s.rinv = F.ld(r0 + 2 * LV - 1);
+    s.cf = {F.ld(c0 + 4 * (LV - 1)), F.ld(c0 + 4 * (LV - 1) + 1)};
+    s.cinv = {F.ld(c0 + 4 * LV - 2), F.ld(c0 + 4 * LV - 1)};
 }
 
 template <bool ROW, int LV, int l>
 __device__ __forceinline__ void pcr_rc_level(const Lane &L, const SysFactors<LV> &s, double &b, cplx &c)
 {
-    constexpr int st = 1 << l;
-    const double b_lo = keep_m(L.m_lo[l], from_lo<ROW, st>(L, b)), b_hi = keep_m(L.m_hi[l], from_hi<ROW, st>(L, b));
-    const cplx c_lo = {keep_m(L.m_lo[l], from_lo<ROW, st>(L, c.r)), keep_m(L.m_lo[l], from_lo<ROW, st>(L, c.i))};
-    const cplx c_hi = {keep_m(L.m_hi[l], from_hi<ROW, st>(L, c.r)), keep_m(L.m_hi[l], from_hi<ROW, st>(L, c.i))};
-    b = b - s.ra[l] * b_lo - s.rg[l] * b_hi;
-    // c -= ca * c_lo + cg * c_hi as eight fused multiply-adds (no separate products and subtractions)
-    double cr = c.r, ci = c.i;
-    cr = __builtin_fma(-s.ca[l].r, c_lo.r, cr); ci = __builtin_fma(-s.ca[l].r, c_lo.i, ci);
-    cr = __builtin_fma(s.ca[l].i, c_lo.i, cr);  ci = __builtin_fma(-s.ca[l].i, c_lo.r, ci);
-    cr = __builtin_fma(-s.cg[l].r, c_hi.r, cr); ci = __builtin_fma(-s.cg[l].r, c_hi.i, ci);
-    cr = __builtin_fma(s.cg[l].i, c_hi.i, cr);  ci = __builtin_fma(-s.cg[l].i, c_hi.r, ci);
-    c = {cr, ci};
-    if constexpr (l + 1 < LV) pcr_rc_level<ROW, LV, l + 1>(L, s, b, c);
+    if constexpr (l + 1 < LV) {
+        constexpr int st = 1 << l;
+        const double b_lo = keep_m(L.m_lo[l], from_lo<ROW, st>(L, b)), b_hi = keep_m(L.m_hi[l], from_hi<ROW, st>(L, b));
+        const cplx c_lo = {keep_m(L.m_lo[l], from_lo<ROW, st>(L, c.r)), keep_m(L.m_lo[l], from_lo<ROW, st>(L, c.i))};
+        const cplx c_hi = {keep_m(L.m_hi[l], from_hi<ROW, st>(L, c.r)), keep_m(L.m_hi[l], from_hi<ROW, st>(L, c.i))};
+        b = b - s.ra[l] * b_lo - s.rg[l] * b_hi;
+        // c -= ca * c_lo + cg * c_hi as eight fused multiply-adds (no separate products and subtractions)
+        double cr = c.r, ci = c.i;
+        cr = __builtin_fma(-s.ca[l].r, c_lo.r, cr); ci = __builtin_fma(-s.ca[l].r, c_lo.i, ci);
+        cr = __builtin_fma(s.ca[l].i, c_lo.i, cr);  ci = __builtin_fma(-s.ca[l].i, c_lo.r, ci);
+        cr = __builtin_fma(-s.cg[l].r, c_hi.r, cr); ci = __builtin_fma(-s.cg[l].r, c_hi.i, ci);
+        cr = __builtin_fma(s.cg[l].i, c_hi.i, cr);  ci = __builtin_fma(-s.cg[l].i, c_hi.r, ci);
+        c = {cr, ci};
+        pcr_rc_level<ROW, LV, l + 1>(L, s, b, c);
+    } else {
+        // top level: one partner, one factor
+        constexpr int st = 1 << (LV - 1);
+        const double b_p = from_partner<ROW, st>(L, b);
+        const cplx c_p = {from_partner<ROW, st>(L, c.r), from_partner<ROW, st>(L, c.i)};
+        b = b - s.rf * b_p;
+        double cr = c.r, ci = c.i;
+        cr = __builtin_fma(-s.cf.r, c_p.r, cr); ci = __builtin_fma(-s.cf.r, c_p.i, ci);
+        cr = __builtin_fma(s.cf.i, c_p.i, cr);  ci = __builtin_fma(-s.cf.i, c_p.r, ci);
+        c = {cr, ci};
+    }
 }
 
 template <bool ROW, int LV>
@@ -1249,6 +1328,14 @@ __device__ __forceinline__ void lane_geometry(int n, Lane &L)
         asm("" : "+v"(L.m_hi[l]));
     }
     L.segmask = ((n >= 64) ? ~0ull : ((1ull << n) - 1ull)) << L.base;
+    {
+        int top = 1;
+        while (2 * top < n) top *= 2;                     // 2^(LV-1): the top stride
+        const bool up = L.z >= top, has = up || (L.z + top < n);
+        L.a_pt = ((up ? lane - top : lane + top) & 63) << 2;
+        L.m_pt = has ? ~0u : 0u;
+        asm("" : "+v"(L.m_pt));
+    }
     L.d3n = {(double)(3 * n), 1.0 / (double)(3 * n)};
     L.d9n = {(double)(9 * n), 1.0 / (double)(9 * n)};
 }

@@ -163,9 +163,12 @@ int default_streams(int64_t n_reactors, int R)
 template <class F> void with_step_kernel(const wt_ensemble *h, F &&f)
 {
     const int n = h->n;
-#ifdef WT_ONLY_LV3   // scratch builds for kernel tuning: n in 5..8 only (n = 8 takes the row-shift variant)
+#if defined(WT_ONLY_LV3)   // scratch builds for kernel tuning: n = 8 only (the row-shift variant)
     (void)n;
     f(wt::step_kernel<3, true>, 64);
+#elif defined(WT_ONLY_LV5)   // ... n in 17..32 only
+    (void)n;
+    f(wt::step_kernel<5, false>, 64);
 #else
     const int lv = levels_for(n);
     if (row_mode(n)) { // n in {2,4,8,16}: every cross-lane move is a DPP row operation
