@@ -517,21 +517,30 @@ __device__ __forceinline__ void mask_reactor_for_lane(const Lane &L, RK &k)
 // The constants are needed by the RHS evaluations only.  Between them (factorisation, Newton solve, error
 // estimate) they would occupy 38 VGPRs of a register file that is already oversubscribed, so they are parked
 // in LDS and fetched at the top of every RHS block: 14 per-reactor words (one copy per reactor, broadcast to
-// its lanes) and 5 per-lane ones.
-constexpr int RK_UNI = 17, RK_LANE = 5, RK_MAXR = 32;   // up to 32 reactors per wavefront (n = 2)
+// its lanes) and 5 per-lane ones (the inlet / outlet / neighbour masks applied once, at parking time).  Where LDS is
+// short (n > 8: every slot is wanted for tridiagonal factors) the per-lane words are not parked but re-masked from
+// four more per-reactor words at every fetch: ten v_and instead of three LDS reads.
+constexpr int RK_UNI = 20, RK_LANE = 5, RK_MAXR = 32;   // up to 32 reactors per wavefront (n = 2)
 // reactors per wavefront a kernel instantiation can meet: LV levels serve n in (2^(LV-1), 2^LV]
 constexpr int rk_maxr(int LV) { return LV <= 1 ? 32 : 64 / ((1 << (LV - 1)) + 1); }
-struct RKStore { double *uni; double *lane; int stride; };   // uni[c * stride], lane[c * 64]: already offset for this lane
+constexpr bool rk_lane_in_lds(int LV) { return LV < 4; }
+constexpr int rk_lane_doubles(int LV) { return rk_lane_in_lds(LV) ? RK_LANE * 64 : 0; }
+// uni[c * stride], lane[c * 64]: already offset for this lane; lane == nullptr: no per-lane words, use the masks
+struct RKStore { double *uni; double *lane; int stride; uint32_t m_has_lo, m_has_hi; bool lane_lds; };   // lane_lds: a compile-time constant of the kernel
+__device__ __forceinline__ double mask64(uint32_t m, double x) { return __hiloint2double(__double2hiint(x) & (int)m, __double2loint(x) & (int)m); }
 
 __device__ __forceinline__ void park_reactor(const RKStore &st, const RK &k)
 {
     const double u[RK_UNI] = {k.Kw, k.Ka1, k.Ka1Ka2, k.KaH, k.cbeta, k.dz, k.u2, k.supp, k.H_in, k.Cl_in, k.T_in, k.T_amb, k.UAr_on,
-                              k.unsupp, k.ricrit, k.flowsum, k.rihulp};
+                              k.unsupp, k.ricrit, k.flowsum,
+                              k.Kex, k.Qv, k.has_acid ? k.acid_dH : 0.0, k.has_cl ? k.cl_dose : 0.0};   // (rihulp is re-derived from ricrit)
     const double l[RK_LANE] = {k.Kex_hi, k.Qv_in, k.Qv_out, k.acid0, k.dose0};
 #pragma unroll
     for (int c = 0; c < RK_UNI; ++c) st.uni[c * st.stride] = u[c];   // every lane of the reactor stores the same value
+    if (st.lane_lds) {
 #pragma unroll
-    for (int c = 0; c < RK_LANE; ++c) st.lane[c * 64] = l[c];
+        for (int c = 0; c < RK_LANE; ++c) st.lane[c * 64] = l[c];
+    }
 }
 
 __device__ __forceinline__ RK fetch_reactor(const RKStore &st)
@@ -540,8 +549,15 @@ __device__ __forceinline__ RK fetch_reactor(const RKStore &st)
     k.Kw = st.uni[0 * st.stride]; k.Ka1 = st.uni[1 * st.stride]; k.Ka1Ka2 = st.uni[2 * st.stride]; k.KaH = st.uni[3 * st.stride];
     k.cbeta = st.uni[4 * st.stride]; k.dz = st.uni[5 * st.stride]; k.u2 = st.uni[6 * st.stride]; k.supp = st.uni[7 * st.stride];
     k.H_in = st.uni[8 * st.stride]; k.Cl_in = st.uni[9 * st.stride]; k.T_in = st.uni[10 * st.stride]; k.T_amb = st.uni[11 * st.stride];
-    k.UAr_on = st.uni[12 * st.stride]; k.unsupp = st.uni[13 * st.stride]; k.ricrit = st.uni[14 * st.stride]; k.rihulp = st.uni[16 * st.stride];
-    k.Kex_hi = st.lane[0 * 64]; k.Qv_in = st.lane[1 * 64]; k.Qv_out = st.lane[2 * 64]; k.acid0 = st.lane[3 * 64]; k.dose0 = st.lane[4 * 64];
+    k.UAr_on = st.uni[12 * st.stride]; k.unsupp = st.uni[13 * st.stride]; k.ricrit = st.uni[14 * st.stride]; k.rihulp = 0.5 * ulp_above_pos(k.ricrit);
+    if (st.lane_lds) {
+        k.Kex_hi = st.lane[0 * 64]; k.Qv_in = st.lane[1 * 64]; k.Qv_out = st.lane[2 * 64]; k.acid0 = st.lane[3 * 64]; k.dose0 = st.lane[4 * 64];
+    } else {   // the same values as mask_reactor_for_lane() made: zero where the zone has no such term
+        const double Kex = st.uni[16 * st.stride], Qv = st.uni[17 * st.stride];
+        k.Kex_hi = mask64(st.m_has_hi, Kex);
+        k.Qv_in = mask64(~st.m_has_lo, Qv); k.Qv_out = mask64(~st.m_has_hi, Qv);
+        k.acid0 = mask64(~st.m_has_lo, st.uni[18 * st.stride]); k.dose0 = mask64(~st.m_has_lo, st.uni[19 * st.stride]);
+    }
     return k;
 }
 
@@ -765,7 +781,7 @@ constexpr int fstore_lds_slots(int LV)
 {
     if (LV >= 6) return fstore_total_slots(LV) - 3 * (2 * LV);                        // n > 32: three wavefronts per CU either way; registers measured faster
     const int budget = 40960;                                                         // bytes per wavefront at four per CU
-    const int fixed = (RK_UNI * rk_maxr(LV) + RK_LANE * 64 + RK_MAXR) * 8;            // LdsMap: reactor constants, history base, reactor indices
+    const int fixed = (RK_UNI * rk_maxr(LV) + rk_lane_doubles(LV) + rk_maxr(LV)) * 8;     // LdsMap: reactor constants, history base, reactor indices
     const int fit = (budget - fixed) / 512;
     return fit < fstore_total_slots(LV) ? fit : fstore_total_slots(LV);
 }
@@ -1351,8 +1367,8 @@ __device__ __forceinline__ bool lane_setup(int64_t r0, int64_t r1, int n, int R,
 
 // LDS of one wavefront, ONE array: [reactor constants | history base | factor store, reused between outer steps as StepIO]
 template <int LV> struct LdsMap {
-    static constexpr int RK_DOUBLES = RK_UNI * rk_maxr(LV) + RK_LANE * 64;
-    static constexpr int HIST_DOUBLES = RK_MAXR;                          // 2 x RK_MAXR ints: history base, reactor index of each segment
+    static constexpr int RK_DOUBLES = RK_UNI * rk_maxr(LV) + rk_lane_doubles(LV);
+    static constexpr int HIST_DOUBLES = rk_maxr(LV);                      // 2 x rk_maxr ints: history base, reactor index of each segment
     static constexpr int F_DOUBLES = FSlots<LV>::LDS_SLOTS * 64;
     static constexpr int IO_DOUBLES = (int)((sizeof(wts::StepIO) + 7) / 8);
     static constexpr int TAIL_DOUBLES = F_DOUBLES > IO_DOUBLES ? F_DOUBLES : IO_DOUBLES;
@@ -1497,9 +1513,9 @@ __device__ __forceinline__ void run_item(ArgPtr pa, const Lane &L, double *lds, 
     const double dt = a->dt;
     const int step_limit = a->step_limit, sens_on = a->sens.on, plc_on = a->sens.plc_on;
     const bool want_diag = a->wave_diag != nullptr;
-    const RKStore ks = {lds + seg, lds + RK_UNI * rk_maxr(LV) + lane, rk_maxr(LV)};
+    const RKStore ks = {lds + seg, lds + RK_UNI * rk_maxr(LV) + lane, rk_maxr(LV), L.m_lo[0], L.m_hi[0], rk_lane_in_lds(LV)};
     int *hist0 = reinterpret_cast<int *>(lds + M::RK_DOUBLES);
-    int *rix = hist0 + RK_MAXR;                       // reactor index of each segment, for the sensor / PLC lanes
+    int *rix = hist0 + rk_maxr(LV);                   // reactor index of each segment, for the sensor / PLC lanes
     double *lds_factors = lds + M::RK_DOUBLES + M::HIST_DOUBLES;
     wts::StepIO &io = *reinterpret_cast<wts::StepIO *>(lds_factors);
 
