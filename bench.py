@@ -265,6 +265,7 @@ def run_rank(args) -> int:
     n_launch, launch_sum_ms, launch_max_ms = ens.launch_stats() if ens is not None else (0, 0.0, 0.0)
     if ens is not None:
         ens.launch_timing(False)
+        sched = ens.schedule()       # as it stands after the run: "redeals" says whether the cost-aware placement ever acted
 
     el = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=dev)
     if use_dist:
