@@ -580,6 +580,8 @@ struct PropT { double kT, rho; bool bad; };
 // the step's results makes every step complete for all points before the next one starts (NS = 1: nothing to do).
 template <int NS> __device__ __forceinline__ void row_fence(double (&v)[NS])
 {
+    // (one point: nothing to interleave, but the fence keeps the compiler from merging this section with the next)
+    if constexpr (NS == 1) asm volatile("" : "+v"(v[0]));
     if constexpr (NS == 2) asm volatile("" : "+v"(v[0]), "+v"(v[1]));
     if constexpr (NS == 3) asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]));
     if constexpr (NS == 4) asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));
@@ -1476,6 +1478,7 @@ __device__ __forceinline__ void rhs_points(const Lane &L, const RKStore &ks, Arg
         for (int s = 0; s < NS; ++s) x[s] = y[s][SPH];
         prop_pH_n<NS>(c, k, x, pp);
     }
+    __builtin_amdgcn_sched_barrier(0);   // the next section's constants are fetched when this one is through (SGPR budget)
     {
         ArgPtr a = fresh(pa);
         const KT c = load_kt(&a->kt);
