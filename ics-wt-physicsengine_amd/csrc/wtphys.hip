@@ -528,6 +528,12 @@ int wt_ensemble_launch_timing(wt_ensemble *h, int enable)
     if (!h) return fail(WT_E_ARG, "NULL handle");
     h->time_launches = enable != 0;
     h->lt_used = 0;
+    // the first few event pairs exist before the timed region starts (event creation is not part of a launch)
+    while (enable && h->lt_pool.size() < 16) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) break;
+        h->lt_pool.push_back(e);
+    }
     return WT_OK;
 }
 
