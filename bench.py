@@ -348,7 +348,8 @@ def run_rank(args) -> int:
             # how often a group's state returns to memory depends on it, so a figure is only quoted for a run of the
             # same zone count and item length as the profiled one, never scaled from another
             tr = _profile_json("traffic.json")
-            entry = (tr or {}).get("by_steps_per_item", {}).get(str(item_steps)) if tr and tr.get("zones") == n else None
+            entry = ((tr or {}).get("by_steps_per_item", {}).get(str(item_steps))
+                     if tr and tr.get("zones") == n and not args.sensors else None)      # (the sensor suite adds traffic of its own)
             traffic = entry["hbm_bytes_per_zone_step"] * zs_per_launch if entry else None
             fl = _profile_json("pmc_fp64.json")
             compute = None
