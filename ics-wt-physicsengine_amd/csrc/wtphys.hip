@@ -73,10 +73,10 @@ struct wt_ensemble {
     // WT_PLACE_MIN (history before a re-deal), WT_Q_TICKETS (forces the launch split), WT_FULL_WAVES
     int knob_item = 0; int64_t knob_place_min = 0, knob_tickets = 0;
     // sticky record of a launch that did not advance every group (device word + pinned host mirror)
-    int32_t *q_sticky = nullptr;
+    int32_t *q_sticky = nullptr;   // device view of err_host (host-coherent pinned memory: the check kernel writes it in place)
     // one contiguous snapshot of a small ensemble: packed on the device, one copy into pinned memory
     void *snap_dev = nullptr, *snap_host = nullptr; size_t snap_bytes = 0;
-    int32_t *err_host = nullptr;   // pinned: the sticky word of ensembles too large for the packed snapshot
+    int32_t *err_host = nullptr;   // two words, each only ever set to 1: [0] a hand-off timed out, [1] a group was left behind
     int64_t redeals = 0;          // times the slots were re-dealt (bench.py reports it)
     int n_sub = 1, chunk_steps = WT_DEFAULT_CHUNK;
     int step_limit = 2000;    // attempts per outer step before a reactor is given up (reference: unlimited)
@@ -243,7 +243,7 @@ const char *k_incomplete = "a step launch did not advance every wavefront-group 
 // queue the copy of the sticky launch-error word (pinned destination) behind what is already on the stream
 int fetch_sticky(wt_ensemble *h)
 {
-    HIP_TRY(hipMemcpyAsync(h->err_host, h->q_sticky, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    (void)h;   // nothing to copy: the record lives in host-coherent memory, valid once the stream is synchronised
     return WT_OK;
 }
 
@@ -318,7 +318,6 @@ int wt_ensemble_create(int64_t n_reactors, int n_zones, int device, const double
     ALLOC(h->q_ctrl, sizeof(int32_t) * wt::Q_WORDS);
     ALLOC(h->q_slots, sizeof(unsigned long long) * (size_t)h->q_cap);
     ALLOC(h->q_next, sizeof(int32_t) * (size_t)h->n_groups);
-    ALLOC(h->q_sticky, sizeof(int32_t));
     {   // small ensembles (the drop-in's N = 1 above all) are downloaded as one packed image through pinned memory
         const size_t image = sizeof(double) * (6 * N * nz + 2 * N) + sizeof(uint32_t) * (N + 1);
         if (image <= WT_SNAPSHOT_PACK_MAX) {
@@ -326,8 +325,9 @@ int wt_ensemble_create(int64_t n_reactors, int n_zones, int device, const double
             ALLOC(h->snap_dev, h->snap_bytes);
             if (hipHostMalloc(&h->snap_host, h->snap_bytes, hipHostMallocDefault) != hipSuccess) { cleanup(); return fail(WT_E_HIP, "hipHostMalloc failed"); }
         }
-        if (hipHostMalloc((void **)&h->err_host, sizeof(int32_t), hipHostMallocDefault) != hipSuccess) { cleanup(); return fail(WT_E_HIP, "hipHostMalloc failed"); }
-        *h->err_host = 0;
+        if (hipHostMalloc((void **)&h->err_host, 2 * sizeof(int32_t), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) { cleanup(); return fail(WT_E_HIP, "hipHostMalloc failed"); }
+        h->err_host[0] = h->err_host[1] = 0;
+        if (hipHostGetDevicePointer((void **)&h->q_sticky, h->err_host, 0) != hipSuccess) { cleanup(); return fail(WT_E_HIP, "hipHostGetDevicePointer failed"); }
     }
     if (const char *e = getenv("WT_Q_ITEM")) h->knob_item = atoi(e);
     if (const char *e = getenv("WT_PLACE_MIN")) h->knob_place_min = atoll(e);
@@ -353,7 +353,6 @@ int wt_ensemble_create(int64_t n_reactors, int n_zones, int device, const double
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemsetAsync(h->q_ctrl, 0, sizeof(int32_t) * wt::Q_WORDS, h->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(h->q_sticky, 0, sizeof(int32_t), h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     if (e != hipSuccess) { cleanup(); return fail(WT_E_HIP, std::string("upload: ") + hipGetErrorString(e)); }
     *out = h;
@@ -367,7 +366,7 @@ int wt_ensemble_destroy(wt_ensemble *h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->trace) (void)hipFree(h->trace);
     void *ptrs[] = {h->par, h->bc, h->pH, h->Cl, h->T, h->time, h->flow, h->dH, h->dRho, h->dK, h->status, h->stats, h->wave_diag,
-                    h->bad_T, h->q_ctrl, h->q_slots, h->q_next, h->perm, h->cost, h->place_hist, h->q_sticky, h->snap_dev};
+                    h->bad_T, h->q_ctrl, h->q_slots, h->q_next, h->perm, h->cost, h->place_hist, h->snap_dev};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (int s = 0; s < WT_MAX_STREAMS; ++s) {
         if (h->sub_stream[s]) { (void)hipStreamSynchronize(h->sub_stream[s]); (void)hipStreamDestroy(h->sub_stream[s]); }
@@ -806,7 +805,7 @@ int wt_ensemble_queue_error(wt_ensemble *h, int *error)
     int rc;
     if ((rc = fetch_sticky(h))) return rc;
     HIP_TRY(hipStreamSynchronize(h->stream));
-    *error = *h->err_host;      // bit 0: hand-off timed out, bit 1: a group was left behind; sticky until the handle is destroyed
+    *error = (h->err_host[0] ? 1 : 0) | (h->err_host[1] ? 2 : 0);      // bit 0: hand-off timed out, bit 1: a group was left behind; sticky until the handle is destroyed
     return WT_OK;
 }
 
@@ -848,7 +847,7 @@ int wt_ensemble_synchronize(wt_ensemble *h)
     int rc;
     if ((rc = fetch_sticky(h))) return rc;
     HIP_TRY(hipStreamSynchronize(h->stream));
-    if (*h->err_host) return fail(WT_E_HIP, k_incomplete);
+    if (h->err_host[0] | h->err_host[1]) return fail(WT_E_HIP, k_incomplete);
     return WT_OK;
 }
 
@@ -898,7 +897,7 @@ int wt_ensemble_get_state(wt_ensemble *h, double *pH, double *Cl, double *T, dou
     if ((rc = d2h(h, flow, h->flow, sizeof(double) * h->N))) return rc;
     if ((rc = fetch_sticky(h))) return rc;
     HIP_TRY(hipStreamSynchronize(h->stream));
-    if (*h->err_host) return fail(WT_E_HIP, k_incomplete);
+    if (h->err_host[0] | h->err_host[1]) return fail(WT_E_HIP, k_incomplete);
     return WT_OK;
 }
 
@@ -916,7 +915,7 @@ int wt_ensemble_get_snapshot(wt_ensemble *h, double *pH, double *Cl, double *T, 
     if ((rc = d2h(h, flags, h->status, sizeof(uint32_t) * h->N))) return rc;
     if ((rc = fetch_sticky(h))) return rc;
     HIP_TRY(hipStreamSynchronize(h->stream));
-    if (*h->err_host) return fail(WT_E_HIP, k_incomplete);
+    if (h->err_host[0] | h->err_host[1]) return fail(WT_E_HIP, k_incomplete);
     return WT_OK;
 }
 
@@ -941,7 +940,7 @@ int wt_ensemble_get_status(wt_ensemble *h, uint32_t *flags)
     int rc;
     if ((rc = fetch_sticky(h))) return rc;
     HIP_TRY(hipStreamSynchronize(h->stream));
-    if (*h->err_host) return fail(WT_E_HIP, k_incomplete);
+    if (h->err_host[0] | h->err_host[1]) return fail(WT_E_HIP, k_incomplete);
     return WT_OK;
 }
 
