@@ -767,6 +767,15 @@ __device__ __forceinline__ bool rhs_full(const Lane &L, const KP &cp, const KT &
 struct Jac {
     double pp[3], cc[3], tt[3], pt[3], ct[3], cp;
 };
+// The inter-zone exchange depends on temperature through the stratification switch only, a step function: unless a
+// finite-difference perturbation happens to flip a switch, the pH rows do not see T at all and the Cl rows see their
+// own zone's T only (the Arrhenius rate) -- exact zeros, column by column.  A wavefront whose lanes all find them zero
+// skips the neighbours' T increments in every solve (12 cross-lane moves and 15 fused multiply-adds of a Newton
+// iteration): adding the exact zeros would not change a bit.
+__device__ __forceinline__ bool jac_t_dense(const Jac &J)
+{
+    return (J.pt[0] != 0.0) || (J.pt[1] != 0.0) || (J.pt[2] != 0.0) || (J.ct[0] != 0.0) || (J.ct[2] != 0.0);
+}
 
 // PCR-factored tridiagonal systems (real and complex shift) live in LDS, not in
 // registers: slot-major [slot][64 lanes] doubles, so lane l of a wavefront touches
@@ -819,6 +828,43 @@ __device__ __forceinline__ void pcr_factor_level_all(const Lane &L, double ar[3]
 {
     using S = FSlots<LV>;
     constexpr int s = 1 << l;
+    if constexpr (l == 0) {
+        // Level 0: the off-diagonals of the complex-shift systems are still the real ones (-J's bands, imaginary part
+        // exactly 0), so their neighbours' values are the real systems' (moved once, not three times) and every
+        // product with a zero imaginary part drops out -- the same bits with 16 cross-lane moves and 14 fp64
+        // instructions less per system.
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const double a0 = ar[k], c0 = cr[k];
+            const double id = rcp(dr[k]);
+            const double id_lo = from_lo<ROW, s>(L, id), id_hi = from_hi<ROW, s>(L, id);
+            const double a_lo = keep_m(L.m_lo[l], from_lo<ROW, s>(L, a0)), c_lo = keep_m(L.m_lo[l], from_lo<ROW, s>(L, c0));
+            const double a_hi = keep_m(L.m_hi[l], from_hi<ROW, s>(L, a0)), c_hi = keep_m(L.m_hi[l], from_hi<ROW, s>(L, c0));
+            const double al = a0 * keep_m(L.m_lo[l], id_lo);
+            const double ga = c0 * keep_m(L.m_hi[l], id_hi);
+            dr[k] = dr[k] - al * c_lo - ga * a_hi;
+            ar[k] = -al * a_lo;
+            cr[k] = -ga * c_hi;
+            F.st(k * S::RS + 2 * l, al); F.st(k * S::RS + 2 * l + 1, ga);
+            // complex shift: alpha = a / d_lo, gamma = c / d_hi with real a, c
+            const cplx cid = cinv(dc[k]);
+            const cplx i_lo = cfrom_lo<ROW, s>(L, cid), i_hi = cfrom_hi<ROW, s>(L, cid);
+            const cplx il = {keep_m(L.m_lo[l], i_lo.r), keep_m(L.m_lo[l], i_lo.i)};
+            const cplx ih = {keep_m(L.m_hi[l], i_hi.r), keep_m(L.m_hi[l], i_hi.i)};
+            const cplx cal = {a0 * il.r, a0 * il.i};
+            const cplx cga = {c0 * ih.r, c0 * ih.i};
+            double dre = dc[k].r, dim = dc[k].i;
+            dre = __builtin_fma(-cal.r, c_lo, dre); dim = __builtin_fma(-cal.i, c_lo, dim);
+            dre = __builtin_fma(-cga.r, a_hi, dre); dim = __builtin_fma(-cga.i, a_hi, dim);
+            dc[k] = {dre, dim};
+            ac[k] = {-(cal.r * a_lo), -(cal.i * a_lo)};
+            cc[k] = {-(cga.r * c_hi), -(cga.i * c_hi)};
+            const int c0s = S::CB + k * S::CS + 4 * l;
+            F.st(c0s, cal.r); F.st(c0s + 1, cal.i); F.st(c0s + 2, cga.r); F.st(c0s + 3, cga.i);
+        }
+        if constexpr (l + 2 < LV) pcr_factor_level_all<ROW, LV, l + 1>(L, ar, dr, cr, ac, dc, cc, F);
+        return;
+    }
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         // real shift.  Every lane inverts its own diagonal once and the neighbours fetch the reciprocal (the same
@@ -950,7 +996,7 @@ __device__ __forceinline__ void pcr_real_level(const Lane &L, const RealFactors<
 }
 
 template <bool ROW, int LV>
-__device__ __forceinline__ void solve_real(const Lane &L, const Jac &J, const FStore<LV> &F, double b[3])
+__device__ __forceinline__ void solve_real(const Lane &L, const Jac &J, const FStore<LV> &F, double b[3], bool t_local)
 {
     // (many levels: a system's factors are fetched when its turn comes, or the three sets together crowd the register file)
     RealFactors<LV> fT, fP, fC;
@@ -960,13 +1006,20 @@ __device__ __forceinline__ void solve_real(const Lane &L, const Jac &J, const FS
     pcr_real_level<ROW, LV, 0>(L, fT, xT);
     xT *= fT.inv;
     if constexpr (LV >= 4) load_real<LV>(F, 1, fP);
-    const double xT_lo_r = from_lo<ROW, 1>(L, xT), xT_hi_r = from_hi<ROW, 1>(L, xT);
-    const double xT_lo = keep_m(L.m_lo[0], xT_lo_r), xT_hi = keep_m(L.m_hi[0], xT_hi_r); // J.pt/ct[0,2] are 0 there
-    double xP = b[SPH] + (J.pt[0] * xT_lo + J.pt[1] * xT + J.pt[2] * xT_hi);
+    double xP, tC;
+    if (t_local) {      // (wave-uniform) no row of this wavefront couples to a neighbour's temperature: see jac_t_local
+        xP = b[SPH];
+        tC = J.ct[1] * xT;
+    } else {
+        const double xT_lo_r = from_lo<ROW, 1>(L, xT), xT_hi_r = from_hi<ROW, 1>(L, xT);
+        const double xT_lo = keep_m(L.m_lo[0], xT_lo_r), xT_hi = keep_m(L.m_hi[0], xT_hi_r); // J.pt/ct[0,2] are 0 there
+        xP = b[SPH] + (J.pt[0] * xT_lo + J.pt[1] * xT + J.pt[2] * xT_hi);
+        tC = J.ct[0] * xT_lo + J.ct[1] * xT + J.ct[2] * xT_hi;
+    }
     pcr_real_level<ROW, LV, 0>(L, fP, xP);
     xP *= fP.inv;
     if constexpr (LV >= 4) load_real<LV>(F, 2, fC);
-    double xC = b[SCL] + (J.ct[0] * xT_lo + J.ct[1] * xT + J.ct[2] * xT_hi) + J.cp * xP;
+    double xC = b[SCL] + tC + J.cp * xP;
     pcr_real_level<ROW, LV, 0>(L, fC, xC);
     xC *= fC.inv;
     b[SPH] = xP; b[SCL] = xC; b[STT] = xT;
@@ -1029,7 +1082,7 @@ __device__ __forceinline__ void pcr_rc_level(const Lane &L, const SysFactors<LV>
 
 template <bool ROW, int LV>
 __device__ __forceinline__ void solve_rc(const Lane &L, const Jac &J, const FStore<LV> &F,
-                                         double br[3], double cr[3], double ci[3])
+                                         double br[3], double cr[3], double ci[3], bool t_local)
 {
     // Few levels: all three systems' factors are fetched ahead of their use (one exposed LDS round trip instead
     // of three).  Many levels (n > 8): 6 LV + 3 doubles per system -- fetched system by system, or the three sets
@@ -1042,20 +1095,27 @@ __device__ __forceinline__ void solve_rc(const Lane &L, const Jac &J, const FSto
     pcr_rc_level<ROW, LV, 0>(L, sT, xT, zT);
     xT *= sT.rinv; zT = cmul(zT, sT.cinv);
     if constexpr (LV < 4) load_sys<LV>(F, 2, sC); else load_sys<LV>(F, 1, sP);
-    const double xT_lo = keep_m(L.m_lo[0], from_lo<ROW, 1>(L, xT)), xT_hi = keep_m(L.m_hi[0], from_hi<ROW, 1>(L, xT));
-    const cplx zT_lo = {keep_m(L.m_lo[0], from_lo<ROW, 1>(L, zT.r)), keep_m(L.m_lo[0], from_lo<ROW, 1>(L, zT.i))};
-    const cplx zT_hi = {keep_m(L.m_hi[0], from_hi<ROW, 1>(L, zT.r)), keep_m(L.m_hi[0], from_hi<ROW, 1>(L, zT.i))};
-    // pH block: rhs += J_pT x_T
-    double xP = br[SPH] + (J.pt[0] * xT_lo + J.pt[1] * xT + J.pt[2] * xT_hi);
-    cplx zP = {cr[SPH] + (J.pt[0] * zT_lo.r + J.pt[1] * zT.r + J.pt[2] * zT_hi.r),
-               ci[SPH] + (J.pt[0] * zT_lo.i + J.pt[1] * zT.i + J.pt[2] * zT_hi.i)};
+    double xP, tC; cplx zP, uC;
+    if (t_local) {      // (wave-uniform) no row of this wavefront couples to a neighbour's temperature: see jac_t_local
+        xP = br[SPH]; zP = {cr[SPH], ci[SPH]};
+        tC = J.ct[1] * xT; uC = {J.ct[1] * zT.r, J.ct[1] * zT.i};
+    } else {
+        const double xT_lo = keep_m(L.m_lo[0], from_lo<ROW, 1>(L, xT)), xT_hi = keep_m(L.m_hi[0], from_hi<ROW, 1>(L, xT));
+        const cplx zT_lo = {keep_m(L.m_lo[0], from_lo<ROW, 1>(L, zT.r)), keep_m(L.m_lo[0], from_lo<ROW, 1>(L, zT.i))};
+        const cplx zT_hi = {keep_m(L.m_hi[0], from_hi<ROW, 1>(L, zT.r)), keep_m(L.m_hi[0], from_hi<ROW, 1>(L, zT.i))};
+        // pH block: rhs += J_pT x_T
+        xP = br[SPH] + (J.pt[0] * xT_lo + J.pt[1] * xT + J.pt[2] * xT_hi);
+        zP = {cr[SPH] + (J.pt[0] * zT_lo.r + J.pt[1] * zT.r + J.pt[2] * zT_hi.r),
+              ci[SPH] + (J.pt[0] * zT_lo.i + J.pt[1] * zT.i + J.pt[2] * zT_hi.i)};
+        tC = J.ct[0] * xT_lo + J.ct[1] * xT + J.ct[2] * xT_hi;
+        uC = {J.ct[0] * zT_lo.r + J.ct[1] * zT.r + J.ct[2] * zT_hi.r, J.ct[0] * zT_lo.i + J.ct[1] * zT.i + J.ct[2] * zT_hi.i};
+    }
     pcr_rc_level<ROW, LV, 0>(L, sP, xP, zP);
     xP *= sP.rinv; zP = cmul(zP, sP.cinv);
     if constexpr (LV >= 4) load_sys<LV>(F, 2, sC);
     // chlorine block: rhs += J_cT x_T + J_cp x_p
-    double xC = br[SCL] + (J.ct[0] * xT_lo + J.ct[1] * xT + J.ct[2] * xT_hi) + J.cp * xP;
-    cplx zC = {cr[SCL] + (J.ct[0] * zT_lo.r + J.ct[1] * zT.r + J.ct[2] * zT_hi.r) + J.cp * zP.r,
-               ci[SCL] + (J.ct[0] * zT_lo.i + J.ct[1] * zT.i + J.ct[2] * zT_hi.i) + J.cp * zP.i};
+    double xC = br[SCL] + tC + J.cp * xP;
+    cplx zC = {cr[SCL] + uC.r + J.cp * zP.r, ci[SCL] + uC.i + J.cp * zP.i};
     pcr_rc_level<ROW, LV, 0>(L, sC, xC, zC);
     xC *= sC.rinv; zC = cmul(zC, sC.cinv);
     br[SPH] = xP; br[SCL] = xC; br[STT] = xT;
@@ -1576,7 +1636,8 @@ __device__ __forceinline__ void run_item(ArgPtr pa, const Lane &L, double *lds, 
             Flag have_fac{fl, 1u << 0}, have_old{fl, 1u << 1}, have_old_l{fl, 1u << 2}, have_sol{fl, 1u << 3}, current_jac{fl, 1u << 4},
                  have_lu{fl, 1u << 5}, rejected{fl, 1u << 6}, keep_h{fl, 1u << 7}, have_norm_old{fl, 1u << 8}, have_rate{fl, 1u << 9},
                  bad{fl, 1u << 10}, failed{fl, 1u << 11}, fv{fl, 1u << 12}, need_jac{fl, 1u << 13},
-                 limit_hit{fl, 1u << 16}, pend_f{fl, 1u << 17}, jac_after_fnew{fl, 1u << 18};
+                 limit_hit{fl, 1u << 16}, pend_f{fl, 1u << 17}, jac_after_fnew{fl, 1u << 18},
+                 j_dense{fl, 1u << 19};               // this lane's Jacobian couples a row to a neighbour's temperature
             fv = f_valid;
             double fac[3] = {0, 0, 0};
             double t = t_out, t_bound = t_out + dt, max_step = fmin(dt, 10.0);
@@ -1826,7 +1887,7 @@ __device__ __forceinline__ void run_item(ArgPtr pa, const Lane &L, double *lds, 
                             fcr[q] = re - (Mcr * W[1][q] - Mci * W[2][q]);
                             fci[q] = im - (Mcr * W[2][q] + Mci * W[1][q]);
                         }
-                        solve_rc<ROW, LV>(L, J, F, fr, fcr, fci);
+                        solve_rc<ROW, LV>(L, J, F, fr, fcr, fci, __ballot(j_dense) == 0ull);
                         double ssum = 0.0;
 #pragma unroll
                         for (int q = 0; q < 3; ++q) {
@@ -1866,7 +1927,7 @@ __device__ __forceinline__ void run_item(ArgPtr pa, const Lane &L, double *lds, 
                             err[q] = f[q] + ZE;
                             esc[q] = kze.atol + fmax(fabs(yc[q]), fabs(yc[q] + z2)) * kze.rtol;
                         }
-                        solve_real<ROW, LV>(L, J, F, err);
+                        solve_real<ROW, LV>(L, J, F, err, __ballot(j_dense) == 0ull);
                         error_norm = rms3<ROW>(L, err, esc);
                         safety = 0.9 * (2 * NEWTON_MAXITER + 1) / (2 * NEWTON_MAXITER + n_iter);
                         if (WT_RARE(rejected && error_norm > 1)) {
@@ -1892,7 +1953,7 @@ __device__ __forceinline__ void run_item(ArgPtr pa, const Lane &L, double *lds, 
                         err[q] = Fe[0][q] + ZE;
                         esc[q] = kze.atol + fmax(fabs(yc[q]), fabs(yc[q] + z2)) * kze.rtol;
                     }
-                    solve_real<ROW, LV>(L, J, F, err);
+                    solve_real<ROW, LV>(L, J, F, err, __ballot(j_dense) == 0ull);
                     error_norm = rms3<ROW>(L, err, esc);
                     if (error_norm > 1) reject_step(); else accept_step();
                 } else if (phase == PH_FNEW) {
@@ -1916,6 +1977,7 @@ __device__ __forceinline__ void run_item(ArgPtr pa, const Lane &L, double *lds, 
                     asm volatile("" ::: "memory");               // a fresh fetch: do not keep the constants live across the epilogue
                     num_jac<ROW>(L, ks, [&]() { return &fresh(pa)->kt; }, yc, f, fac, hf, J, jbad, jval); cnt_s.njev++;
                     have_fac = hf;
+                    j_dense = jac_t_dense(J);
                     need_jac = false;
                     if (WT_RARE(seg_any(L, jbad))) {
                         if (jbad && !bad) { badstage = 4; badval = jval; }
