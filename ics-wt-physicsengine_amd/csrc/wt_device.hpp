@@ -292,6 +292,8 @@ struct StepArgs {
 enum { Q_AVAIL = 0, Q_HEAD = 1, Q_TAIL = 2, Q_ERROR = 3, Q_TRACE = 4, Q_DONE = 5, Q_WORDS = 16 };
 
 // ---------------------------------------------------------------- lane geometry and cross-lane moves
+typedef __attribute__((address_space(3))) double LdsDouble;
+typedef __attribute__((address_space(3))) char LdsByte;
 struct Divisor { double d, inv; };     // a fixed divisor and RN(1 / d): div_by()
 struct Lane {
     int n, z;
@@ -300,8 +302,9 @@ struct Lane {
     // with a VGPR operand (v_and) keeps the tests out of the scalar register file, where each would be a
     // 64-bit lane mask for the whole solver loop
     uint32_t m_lo[7], m_hi[7];
-    int a_lo[7], a_hi[7];     // ds_bpermute byte addresses of lane -/+ 2^l (segments that straddle DPP rows)
     int a_pt; uint32_t m_pt;  // the one partner of the top cyclic-reduction level (from_partner), and whether it exists
+    int a_me;                 // byte offset of this lane's own cell in the exchange row (8 * lane)
+    LdsDouble *xrow;          // cell 0 of the exchange row (ROW = false kernels; nullptr otherwise): XROW_PAD cells either side
     int base;                 // lane id of zone 0 of this segment
     unsigned long long segmask;
     Divisor d3n, d9n;         // 3n, 9n: component counts of the RMS norms (common.py:63-65, radau.py:105)
@@ -331,7 +334,7 @@ template <bool ROW, int S> __device__ __forceinline__ double from_lo(const Lane 
 {   // value held by lane (this - S)
     if constexpr (ROW && S < 16) return dpp_mov<0x110 + S>(x);      // row_shr:S
     else if constexpr (S == 1) return dpp_mov<0x138>(x);  // wave_shr:1
-    else return bpermute(L.a_lo[ilog2(S)], x);
+    else return bpermute(((L.a_me >> 1) - 4 * S) & 255, x);
 }
 // A value read from outside the segment only ever meets a zero coefficient, so it is
 // enough to make it FINITE: clearing the high dword (sign, exponent, top mantissa bits)
@@ -340,6 +343,30 @@ template <bool ROW, int S> __device__ __forceinline__ double from_lo(const Lane 
 __device__ __forceinline__ double keep_m(uint32_t mask, double x)
 {
     return __hiloint2double(__double2hiint(x) & (int)mask, __double2loint(x));
+}
+
+// Strides that neither a row shift nor the whole-wave shift by one can do (ROW = false, S > 1) go through a row of 64
+// doubles in LDS: every lane stores its value, then loads its neighbours'.  One ds_write_b64 + two ds_read_b64 per
+// double and level where ds_bpermute_b32 needs four moves, at 10-14 cycles each instead of 24 (tools/ubench/lds.hip:
+// four wavefronts of a CU sharing its LDS pipe).  The LDS pipe executes a wavefront's operations in order, so the next
+// value may be stored as soon as the loads of the last one are issued: no wait between exchanges, only before the use.
+// Lane +/- stride is an immediate offset from the lane's own cell (no address registers per level); what a lane reads
+// from beyond the row's ends (its neighbours in the allocation: LdsMap) or from another reactor's cells is masked by its
+// caller like every out-of-segment value.
+constexpr int XROW_PAD = 32, XROW_CELLS = 64 + 2 * XROW_PAD;      // a stand-alone row (self-test kernel) carries padding
+// (To the compiler a lane's store to its own cell and its loads of other cells are unrelated accesses of one thread,
+// free to be reordered; the wave barriers -- no instruction, an ordering point for memory operations -- say otherwise.)
+__device__ __forceinline__ void x_put(const Lane &L, double x)
+{
+    __builtin_amdgcn_wave_barrier();            // the loads of the previous exchange come first
+    *(LdsDouble *)((LdsByte *)L.xrow + L.a_me) = x;
+    __builtin_amdgcn_wave_barrier();            // ... and this exchange's loads after the store
+}
+__device__ __forceinline__ double x_get(const Lane &L, int byte_off) { return *(LdsDouble *)((LdsByte *)L.xrow + byte_off); }
+template <int D> __device__ __forceinline__ double x_rel(const Lane &L)
+{
+    static_assert(D >= -XROW_PAD && D <= XROW_PAD, "stride beyond the padding");
+    return *(LdsDouble *)((LdsByte *)L.xrow + L.a_me + 8 * D);
 }
 
 // At the top level of the cyclic reduction (stride S = 2^(LV-1) >= n/2) a zone has at most ONE partner: zone z - S if
@@ -357,14 +384,21 @@ template <bool ROW, int S> __device__ __forceinline__ double from_partner(const 
     else if constexpr (ROW && S == 2) return dpp_mov<0x4E>(x);       // quad_perm [2,3,0,1]
     else if constexpr (ROW && S == 4) return dpp_merge<0x104, 0x5>(dpp_merge<0x114, 0xA>(x, x), x);   // row_shr:4 -> zones 4..7, row_shl:4 -> zones 0..3
     else if constexpr (ROW && S == 8) return dpp_mov<0x128>(x);      // row_ror:8
-    else return keep_m(L.m_pt, bpermute(L.a_pt, x));
+    else { x_put(L, x); return keep_m(L.m_pt, x_get(L, L.a_pt)); }
 }
 
 template <bool ROW, int S> __device__ __forceinline__ double from_hi(const Lane &L, double x)
 {   // value held by lane (this + S)
     if constexpr (ROW && S < 16) return dpp_mov<0x100 + S>(x);      // row_shl:S
     else if constexpr (S == 1) return dpp_mov<0x130>(x);  // wave_shl:1
-    else return bpermute(L.a_hi[ilog2(S)], x);
+    else return bpermute(((L.a_me >> 1) + 4 * S) & 255, x);
+}
+
+// the values held by lanes (this - S) and (this + S)
+template <bool ROW, int S> __device__ __forceinline__ void both(const Lane &L, double x, double &lo, double &hi)
+{
+    if constexpr (ROW || S == 1) { lo = from_lo<ROW, S>(L, x); hi = from_hi<ROW, S>(L, x); }
+    else { x_put(L, x); lo = x_rel<-S>(L); hi = x_rel<S>(L); }
 }
 
 __device__ __forceinline__ bool seg_any(const Lane &L, bool p) { return (__ballot(p) & L.segmask) != 0ull; }
@@ -791,8 +825,8 @@ constexpr int fstore_total_slots(int LV) { return 3 * (2 * LV) + 3 * (4 * LV); }
 constexpr int fstore_lds_slots(int LV)
 {
     if (LV >= 6) return fstore_total_slots(LV) - 3 * (2 * LV);                        // n > 32: three wavefronts per CU either way; registers measured faster
-    const int budget = 40960;                                                         // bytes per wavefront at four per CU
-    const int fixed = (RK_UNI * rk_maxr(LV) + rk_lane_doubles(LV) + rk_maxr(LV)) * 8;     // LdsMap: reactor constants, history base, reactor indices
+    const int budget = 40960;                                  // bytes per wavefront at four per CU (n > 16: less the exchange row)
+    const int fixed = (RK_UNI * rk_maxr(LV) + rk_lane_doubles(LV) + rk_maxr(LV) + 64) * 8;   // LdsMap: reactor constants, history base, reactor indices, exchange row
     const int fit = (budget - fixed) / 512;
     return fit < fstore_total_slots(LV) ? fit : fstore_total_slots(LV);
 }
@@ -818,6 +852,10 @@ __device__ __forceinline__ cplx cinv(cplx a) { const double q = rcp(a.r * a.r + 
 
 template <bool ROW, int S> __device__ __forceinline__ cplx cfrom_lo(const Lane &L, cplx a) { return {from_lo<ROW, S>(L, a.r), from_lo<ROW, S>(L, a.i)}; }
 template <bool ROW, int S> __device__ __forceinline__ cplx cfrom_hi(const Lane &L, cplx a) { return {from_hi<ROW, S>(L, a.r), from_hi<ROW, S>(L, a.i)}; }
+template <bool ROW, int S> __device__ __forceinline__ void cboth(const Lane &L, cplx a, cplx &lo, cplx &hi)
+{
+    both<ROW, S>(L, a.r, lo.r, hi.r); both<ROW, S>(L, a.i, lo.i, hi.i);
+}
 
 // One cyclic-reduction level of all six systems (three real, three complex shift) at once: the
 // six eliminations are independent, so issuing them together hides the reciprocal / DPP latency
@@ -870,9 +908,8 @@ __device__ __forceinline__ void pcr_factor_level_all(const Lane &L, double ar[3]
         // real shift.  Every lane inverts its own diagonal once and the neighbours fetch the reciprocal (the same
         // bits as inverting the fetched diagonal on both sides, half the reciprocals)
         const double id = rcp(dr[k]);
-        const double id_lo = from_lo<ROW, s>(L, id), id_hi = from_hi<ROW, s>(L, id);
-        const double a_lo = from_lo<ROW, s>(L, ar[k]), c_lo = from_lo<ROW, s>(L, cr[k]);
-        const double a_hi = from_hi<ROW, s>(L, ar[k]), c_hi = from_hi<ROW, s>(L, cr[k]);
+        double id_lo, id_hi, a_lo, a_hi, c_lo, c_hi;
+        both<ROW, s>(L, id, id_lo, id_hi); both<ROW, s>(L, ar[k], a_lo, a_hi); both<ROW, s>(L, cr[k], c_lo, c_hi);
         // a == 0 where there is no lower neighbour (c likewise), so alpha/gamma vanish there by
         // themselves once the foreign operands are finite (keep_m folds into the cross-lane move)
         const double al = ar[k] * keep_m(L.m_lo[l], id_lo);
@@ -886,9 +923,8 @@ __device__ __forceinline__ void pcr_factor_level_all(const Lane &L, double ar[3]
     for (int k = 0; k < 3; ++k) {
         // complex shift, likewise
         const cplx cid = cinv(dc[k]);
-        const cplx i_lo = cfrom_lo<ROW, s>(L, cid), i_hi = cfrom_hi<ROW, s>(L, cid);
-        const cplx a_lo = cfrom_lo<ROW, s>(L, ac[k]), c_lo = cfrom_lo<ROW, s>(L, cc[k]);
-        const cplx a_hi = cfrom_hi<ROW, s>(L, ac[k]), c_hi = cfrom_hi<ROW, s>(L, cc[k]);
+        cplx i_lo, i_hi, a_lo, a_hi, c_lo, c_hi;
+        cboth<ROW, s>(L, cid, i_lo, i_hi); cboth<ROW, s>(L, ac[k], a_lo, a_hi); cboth<ROW, s>(L, cc[k], c_lo, c_hi);
         const cplx il = {keep_m(L.m_lo[l], i_lo.r), keep_m(L.m_lo[l], i_lo.i)};
         const cplx ih = {keep_m(L.m_hi[l], i_hi.r), keep_m(L.m_hi[l], i_hi.i)};
         const cplx al = cmul(ac[k], il);
@@ -987,7 +1023,8 @@ __device__ __forceinline__ void pcr_real_level(const Lane &L, const RealFactors<
 {
     if constexpr (l + 1 < LV) {
         constexpr int st = 1 << l;
-        const double b_lo = from_lo<ROW, st>(L, b), b_hi = from_hi<ROW, st>(L, b);
+        double b_lo, b_hi;
+        both<ROW, st>(L, b, b_lo, b_hi);
         b = b - s.a[l] * keep_m(L.m_lo[l], b_lo) - s.g[l] * keep_m(L.m_hi[l], b_hi);
         pcr_real_level<ROW, LV, l + 1>(L, s, b);
     } else {
@@ -1055,9 +1092,11 @@ __device__ __forceinline__ void pcr_rc_level(const Lane &L, const SysFactors<LV>
 {
     if constexpr (l + 1 < LV) {
         constexpr int st = 1 << l;
-        const double b_lo = keep_m(L.m_lo[l], from_lo<ROW, st>(L, b)), b_hi = keep_m(L.m_hi[l], from_hi<ROW, st>(L, b));
-        const cplx c_lo = {keep_m(L.m_lo[l], from_lo<ROW, st>(L, c.r)), keep_m(L.m_lo[l], from_lo<ROW, st>(L, c.i))};
-        const cplx c_hi = {keep_m(L.m_hi[l], from_hi<ROW, st>(L, c.r)), keep_m(L.m_hi[l], from_hi<ROW, st>(L, c.i))};
+        double b_lo, b_hi; cplx c_lo, c_hi;
+        both<ROW, st>(L, b, b_lo, b_hi); cboth<ROW, st>(L, c, c_lo, c_hi);
+        b_lo = keep_m(L.m_lo[l], b_lo); b_hi = keep_m(L.m_hi[l], b_hi);
+        c_lo = {keep_m(L.m_lo[l], c_lo.r), keep_m(L.m_lo[l], c_lo.i)};
+        c_hi = {keep_m(L.m_hi[l], c_hi.r), keep_m(L.m_hi[l], c_hi.i)};
         b = b - s.ra[l] * b_lo - s.rg[l] * b_hi;
         // c -= ca * c_lo + cg * c_hi as eight fused multiply-adds (no separate products and subtractions)
         double cr = c.r, ci = c.i;
@@ -1395,12 +1434,12 @@ __device__ __forceinline__ void lane_geometry(int n, Lane &L)
     const int seg = lane / n;
     L.n = n; L.z = lane - seg * n;
     L.base = seg * n;
+    L.a_me = lane << 3; L.xrow = nullptr;
     L.has_lo = L.z > 0; L.has_hi = L.z < n - 1;
 #pragma unroll
     for (int l = 0; l < 7; ++l) {
         L.m_lo[l] = (L.z - (1 << l) >= 0) ? ~0u : 0u;
         L.m_hi[l] = (L.z + (1 << l) < n) ? ~0u : 0u;
-        L.a_lo[l] = ((lane - (1 << l)) & 63) << 2; L.a_hi[l] = ((lane + (1 << l)) & 63) << 2;
         // opaque to the optimiser, or `x & mask` is canonicalised back into a select on the compare
         asm("" : "+v"(L.m_lo[l]));
         asm("" : "+v"(L.m_hi[l]));
@@ -1410,7 +1449,7 @@ __device__ __forceinline__ void lane_geometry(int n, Lane &L)
         int top = 1;
         while (2 * top < n) top *= 2;                     // 2^(LV-1): the top stride
         const bool up = L.z >= top, has = up || (L.z + top < n);
-        L.a_pt = ((up ? lane - top : lane + top) & 63) << 2;
+        L.a_pt = ((up ? lane - top : lane + top) & 63) << 3;
         L.m_pt = has ? ~0u : 0u;
         asm("" : "+v"(L.m_pt));
     }
@@ -1434,7 +1473,13 @@ template <int LV> struct LdsMap {
     static constexpr int F_DOUBLES = FSlots<LV>::LDS_SLOTS * 64;
     static constexpr int IO_DOUBLES = (int)((sizeof(wts::StepIO) + 7) / 8);
     static constexpr int TAIL_DOUBLES = F_DOUBLES > IO_DOUBLES ? F_DOUBLES : IO_DOUBLES;
-    static constexpr int TOTAL = RK_DOUBLES + HIST_DOUBLES + TAIL_DOUBLES;
+    // the exchange row of the ROW = false kernels (both(), from_partner()): 64 cells between the reactor constants and
+    // the factor store.  A lane whose neighbour lies outside the wavefront reads up to 2^(LV-2) cells beyond either
+    // end -- constants or factors of this same allocation, masked by the caller like every out-of-segment value.
+    static constexpr int X_OFF = RK_DOUBLES + HIST_DOUBLES, X_DOUBLES = 64;
+    static constexpr int F_OFF = X_OFF + X_DOUBLES;
+    static constexpr int TOTAL = F_OFF + TAIL_DOUBLES;
+    static_assert(X_OFF >= (LV >= 2 ? (1 << (LV - 2)) : 0), "reads below the exchange row must stay inside the allocation");
 };
 
 // The argument block has ~80 pointers; held in SGPRs across the solver loop they would crowd out the loop's own
@@ -1579,7 +1624,7 @@ __device__ __forceinline__ void run_item(ArgPtr pa, const Lane &L, double *lds, 
     const RKStore ks = {lds + seg, lds + RK_UNI * rk_maxr(LV) + lane, rk_maxr(LV), L.m_lo[0], L.m_hi[0], rk_lane_in_lds(LV)};
     int *hist0 = reinterpret_cast<int *>(lds + M::RK_DOUBLES);
     int *rix = hist0 + rk_maxr(LV);                   // reactor index of each segment, for the sensor / PLC lanes
-    double *lds_factors = lds + M::RK_DOUBLES + M::HIST_DOUBLES;
+    double *lds_factors = lds + M::F_OFF;
     wts::StepIO &io = *reinterpret_cast<wts::StepIO *>(lds_factors);
 
     // ---- per-reactor state carried from one outer step to the next (segment-uniform scalars replicated in every lane)
@@ -2144,6 +2189,7 @@ __global__ __launch_bounds__(64) void step_kernel(const StepArgs a_unused)
     Lane L;
     // ROW instantiations serve exactly one zone count (n = 2^LV): a compile-time constant for everything below
     lane_geometry(ROW ? (1 << LV) : fresh(pa)->n, L);
+    if constexpr (!ROW) L.xrow = (LdsDouble *)(lds + LdsMap<LV>::X_OFF);   // cross-lane moves by strides >= 2
     bool exchanged = true;
     int group;
     {
@@ -2267,7 +2313,10 @@ template <bool ROW>
 __global__ __launch_bounds__(64) void shuffle_selftest_kernel(const ShuffleTestArgs a)
 {
     Lane L; int64_t r;
-    if (!lane_setup(0, 64 / a.n, a.n, 64 / a.n, L, r)) { a.out[threadIdx.x] = 0; return; }
+    __shared__ double xrow[XROW_CELLS];
+    const bool present = lane_setup(0, 64 / a.n, a.n, 64 / a.n, L, r);
+    if constexpr (!ROW) L.xrow = (LdsDouble *)xrow + XROW_PAD;
+    if (!present) { a.out[threadIdx.x] = 0; return; }
     const int lane = threadIdx.x & 63;
     const double x = 1000.0 * (lane + 1) + 0.5;
     int bad = 0;
@@ -2276,6 +2325,22 @@ __global__ __launch_bounds__(64) void shuffle_selftest_kernel(const ShuffleTestA
     chk(from_lo<ROW, 2>(L, x), lane - 2, L.z >= 2); chk(from_hi<ROW, 2>(L, x), lane + 2, L.z + 2 < L.n);
     chk(from_lo<ROW, 4>(L, x), lane - 4, L.z >= 4); chk(from_hi<ROW, 4>(L, x), lane + 4, L.z + 4 < L.n);
     chk(from_lo<ROW, 8>(L, x), lane - 8, L.z >= 8); chk(from_hi<ROW, 8>(L, x), lane + 8, L.z + 8 < L.n);
+    {   // the exchange-row moves of the cyclic reduction, every stride, and the top level's one partner
+        double lo, hi;
+        both<ROW, 1>(L, x, lo, hi); chk(lo, lane - 1, L.z >= 1); chk(hi, lane + 1, L.z + 1 < L.n);
+        both<ROW, 2>(L, x, lo, hi); chk(lo, lane - 2, L.z >= 2); chk(hi, lane + 2, L.z + 2 < L.n);
+        both<ROW, 4>(L, x, lo, hi); chk(lo, lane - 4, L.z >= 4); chk(hi, lane + 4, L.z + 4 < L.n);
+        both<ROW, 8>(L, x, lo, hi); chk(lo, lane - 8, L.z >= 8); chk(hi, lane + 8, L.z + 8 < L.n);
+        if constexpr (!ROW) {
+            both<ROW, 16>(L, x, lo, hi); chk(lo, lane - 16, L.z >= 16); chk(hi, lane + 16, L.z + 16 < L.n);
+            both<ROW, 32>(L, x, lo, hi); chk(lo, lane - 32, L.z >= 32); chk(hi, lane + 32, L.z + 32 < L.n);
+            int top = 1;
+            while (2 * top < L.n) top *= 2;
+            const bool up = L.z >= top;
+            const double got = from_partner<false, 64>(L, x);        // (the stride is not used on this path)
+            chk(got, up ? lane - top : lane + top, up || (L.z + top < L.n));
+        }
+    }
     double ref = 0.0;
     for (int j = 0; j < L.n; ++j) ref += 1000.0 * (L.base + j + 1) + 0.5; // exact in fp64 (small integers + halves)
     if (seg_sum<ROW>(L, x) != ref) bad++;
