@@ -34,6 +34,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include "wt_sensors.hpp"
 
 namespace wt {
@@ -302,7 +303,7 @@ struct Lane {
     // with a VGPR operand (v_and) keeps the tests out of the scalar register file, where each would be a
     // 64-bit lane mask for the whole solver loop
     uint32_t m_lo[7], m_hi[7];
-    int a_pt; uint32_t m_pt;  // the one partner of the top cyclic-reduction level (from_partner), and whether it exists
+    uint32_t m_pt;            // whether the one partner of the top cyclic-reduction level (from_partner) exists
     int a_me;                 // byte offset of this lane's own cell in the exchange row (8 * lane)
     LdsDouble *xrow;          // cell 0 of the exchange row (ROW = false kernels; nullptr otherwise): XROW_PAD cells either side
     int base;                 // lane id of zone 0 of this segment
@@ -384,7 +385,7 @@ template <bool ROW, int S> __device__ __forceinline__ double from_partner(const 
     else if constexpr (ROW && S == 2) return dpp_mov<0x4E>(x);       // quad_perm [2,3,0,1]
     else if constexpr (ROW && S == 4) return dpp_merge<0x104, 0x5>(dpp_merge<0x114, 0xA>(x, x), x);   // row_shr:4 -> zones 4..7, row_shl:4 -> zones 0..3
     else if constexpr (ROW && S == 8) return dpp_mov<0x128>(x);      // row_ror:8
-    else { x_put(L, x); return keep_m(L.m_pt, x_get(L, L.a_pt)); }
+    else { x_put(L, x); return keep_m(L.m_pt, x_get(L, L.a_me + ((L.z >= S) ? -8 * S : 8 * S))); }   // (S: the top stride)
 }
 
 template <bool ROW, int S> __device__ __forceinline__ double from_hi(const Lane &L, double x)
@@ -407,7 +408,9 @@ __device__ __forceinline__ bool seg_all(const Lane &L, bool p) { return (__ballo
 // Sum over the n lanes of a segment; every lane of the segment receives the
 // bitwise-identical value (each butterfly step adds the same two operands in
 // both partner lanes; the generic path scans and broadcasts).
-template <bool ROW> __device__ __forceinline__ double seg_sum(const Lane &L, double x)
+// (LV: the kernel's number of cyclic-reduction levels, n <= 2^LV, where the caller knows it: rounds that cannot
+// contribute are not compiled)
+template <bool ROW, int LV = 6> __device__ __forceinline__ double seg_sum(const Lane &L, double x)
 {
     if constexpr (ROW) {
         x += dpp_mov<0xB1>(x);                     // quad_perm [1,0,3,2]
@@ -416,11 +419,33 @@ template <bool ROW> __device__ __forceinline__ double seg_sum(const Lane &L, dou
         if (L.n >= 16) x += dpp_mov<0x140>(x);     // row_mirror
         return x;
     } else {
-        for (int s = 1; s < L.n; s <<= 1) {
-            const double v = __shfl_up(x, s, 64);
-            if (L.z >= s) x += v;
+        // The inclusive scan by strides 1, 2, 4, ... (each lane adds the value 2^k lanes below while that lane is in
+        // the segment), two strides per exchange: lane z forms what lane z - 2s would have added in the skipped
+        // round itself, from the same operands in the same order -- the same bits as one stride per round, in half
+        // the LDS round trips.  Then the last lane's total goes to everyone.
+        auto two = [&](auto S_, double y) {
+            constexpr int S = decltype(S_)::value;
+            x_put(L, y);
+            const double v1 = x_rel<-S>(L), v2 = x_rel<-2 * S>(L), v3 = x_rel<-3 * S>(L);
+            const double t = (L.z >= 3 * S) ? v2 + v3 : v2;
+            y = (L.z >= S) ? y + v1 : y;
+            return (L.z >= 2 * S) ? y + t : y;
+        };
+        x = two(std::integral_constant<int, 1>{}, x);
+        if (LV >= 3 && L.n > 4) x = two(std::integral_constant<int, 4>{}, x);
+        if (LV >= 5 && L.n > 16) {
+            x_put(L, x);
+            const double v1 = x_rel<-16>(L);
+            double t = 0.0;
+            if (LV >= 6 && L.n > 32) {      // (the row's neighbours in the allocation do not reach 48 cells down: clamp)
+                const double v2 = x_get(L, max(L.a_me - 8 * 32, 0)), v3 = x_get(L, max(L.a_me - 8 * 48, 0));
+                t = (L.z >= 48) ? v2 + v3 : v2;
+            }
+            x = (L.z >= 16) ? x + v1 : x;
+            x = (L.z >= 32) ? x + t : x;
         }
-        return __shfl(x, L.base + L.n - 1, 64);
+        x_put(L, x);
+        return x_get(L, (L.base + L.n - 1) << 3);
     }
 }
 
@@ -1375,14 +1400,14 @@ __device__ __forceinline__ void num_jac(const Lane &L, const RKStore &ks, KTP kt
 }
 
 // ---------------------------------------------------------------- helpers
-template <bool ROW>
+template <bool ROW, int LV = 6>
 __device__ __forceinline__ double rms3(const Lane &L, const double x[3], const double sc[3])
 {
     // common.py:63-65 norm(x / scale) over the 3n components of one reactor
     double s = 0.0;
 #pragma unroll
     for (int q = 0; q < 3; ++q) { const double v = x[q] * rcp(sc[q]); s += v * v; }
-    return sqrt_k(div_by(seg_sum<ROW>(L, s), L.d3n));
+    return sqrt_k(div_by(seg_sum<ROW, LV>(L, s), L.d3n));
 }
 
 __device__ __forceinline__ double ulp_above(double t)
@@ -1449,7 +1474,6 @@ __device__ __forceinline__ void lane_geometry(int n, Lane &L)
         int top = 1;
         while (2 * top < n) top *= 2;                     // 2^(LV-1): the top stride
         const bool up = L.z >= top, has = up || (L.z + top < n);
-        L.a_pt = ((up ? lane - top : lane + top) & 63) << 3;
         L.m_pt = has ? ~0u : 0u;
         asm("" : "+v"(L.m_pt));
     }
@@ -1706,7 +1730,7 @@ __device__ __forceinline__ void run_item(ArgPtr pa, const Lane &L, double *lds, 
                 double sc[3];
 #pragma unroll
                 for (int q = 0; q < 3; ++q) sc[q] = ATOL + fabs(yc[q]) * RTOL;
-                d0 = rms3<ROW>(L, yc, sc); d1 = rms3<ROW>(L, f, sc);
+                d0 = rms3<ROW, LV>(L, yc, sc); d1 = rms3<ROW, LV>(L, f, sc);
                 h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 * rcp(d1);
                 h0 = fmin(h0, fabs(t_bound - t));
 #pragma unroll
@@ -1900,7 +1924,7 @@ __device__ __forceinline__ void run_item(ArgPtr pa, const Lane &L, double *lds, 
                     double sc[3], df[3];
 #pragma unroll
                     for (int q = 0; q < 3; ++q) { sc[q] = ATOL + fabs(yc[q]) * RTOL; df[q] = Fe[0][q] - f[q]; }
-                    const double d2 = rms3<ROW>(L, df, sc) * rcp(h0);
+                    const double d2 = rms3<ROW, LV>(L, df, sc) * rcp(h0);
                     double h1;
                     if (d1 <= 1e-15 && d2 <= 1e-15) h1 = fmax(1e-6, h0 * 1e-3);
                     else h1 = root4(0.01 * rcp(fmax(d1, d2)));
@@ -1940,7 +1964,7 @@ __device__ __forceinline__ void run_item(ArgPtr pa, const Lane &L, double *lds, 
                             const double u = fr[q] * is, v = fcr[q] * is, w = fci[q] * is;
                             ssum += u * u + v * v + w * w;
                         }
-                        const double dW_norm = sqrt_k(div_by(seg_sum<ROW>(L, ssum), L.d9n));
+                        const double dW_norm = sqrt_k(div_by(seg_sum<ROW, LV>(L, ssum), L.d9n));
                         if (have_norm_old) { rate = dW_norm * rcp(dW_norm_old); have_rate = true; }
                         const double i1r = rcp(1 - rate);
                         if (have_rate && (rate >= 1 || powi6(rate, NEWTON_MAXITER - kk) * i1r * dW_norm > kn.newton_tol)) {
@@ -1973,7 +1997,7 @@ __device__ __forceinline__ void run_item(ArgPtr pa, const Lane &L, double *lds, 
                             esc[q] = kze.atol + fmax(fabs(yc[q]), fabs(yc[q] + z2)) * kze.rtol;
                         }
                         solve_real<ROW, LV>(L, J, F, err, __ballot(j_dense) == 0ull);
-                        error_norm = rms3<ROW>(L, err, esc);
+                        error_norm = rms3<ROW, LV>(L, err, esc);
                         safety = 0.9 * (2 * NEWTON_MAXITER + 1) / (2 * NEWTON_MAXITER + n_iter);
                         if (WT_RARE(rejected && error_norm > 1)) {
 #pragma unroll
@@ -1999,7 +2023,7 @@ __device__ __forceinline__ void run_item(ArgPtr pa, const Lane &L, double *lds, 
                         esc[q] = kze.atol + fmax(fabs(yc[q]), fabs(yc[q] + z2)) * kze.rtol;
                     }
                     solve_real<ROW, LV>(L, J, F, err, __ballot(j_dense) == 0ull);
-                    error_norm = rms3<ROW>(L, err, esc);
+                    error_norm = rms3<ROW, LV>(L, err, esc);
                     if (error_norm > 1) reject_step(); else accept_step();
                 } else if (phase == PH_FNEW) {
                     // f(y_new) of an accepted step that needs it before anything else can happen:
@@ -2337,7 +2361,9 @@ __global__ __launch_bounds__(64) void shuffle_selftest_kernel(const ShuffleTestA
             int top = 1;
             while (2 * top < L.n) top *= 2;
             const bool up = L.z >= top;
-            const double got = from_partner<false, 64>(L, x);        // (the stride is not used on this path)
+            const double got = top == 1 ? from_partner<false, 1>(L, x) : top == 2 ? from_partner<false, 2>(L, x)
+                             : top == 4 ? from_partner<false, 4>(L, x) : top == 8 ? from_partner<false, 8>(L, x)
+                             : top == 16 ? from_partner<false, 16>(L, x) : from_partner<false, 32>(L, x);
             chk(got, up ? lane - top : lane + top, up || (L.z + top < L.n));
         }
     }
