@@ -872,8 +872,19 @@ template <int LV> struct FSlots {
 };
 
 struct cplx { double r, i; };
-__device__ __forceinline__ cplx cmul(cplx a, cplx b) { return {a.r * b.r - a.i * b.i, a.r * b.i + a.i * b.r}; }
-__device__ __forceinline__ cplx cinv(cplx a) { const double q = rcp(a.r * a.r + a.i * a.i); return {a.r * q, -a.i * q}; }
+// (which product is fused is spelled out: the same solve is inlined in alternative paths -- the systems one by one or
+// two in lock step -- and a reactor must get the same bits whichever its wavefront takes)
+__device__ __forceinline__ cplx cmul(cplx a, cplx b)
+{
+#pragma clang fp contract(off)
+    return {__builtin_fma(a.r, b.r, -(a.i * b.i)), __builtin_fma(a.r, b.i, a.i * b.r)};
+}
+__device__ __forceinline__ cplx cinv(cplx a)
+{
+#pragma clang fp contract(off)
+    const double q = rcp(__builtin_fma(a.r, a.r, a.i * a.i));
+    return {a.r * q, -a.i * q};
+}
 
 template <bool ROW, int S> __device__ __forceinline__ cplx cfrom_lo(const Lane &L, cplx a) { return {from_lo<ROW, S>(L, a.r), from_lo<ROW, S>(L, a.i)}; }
 template <bool ROW, int S> __device__ __forceinline__ cplx cfrom_hi(const Lane &L, cplx a) { return {from_hi<ROW, S>(L, a.r), from_hi<ROW, S>(L, a.i)}; }
@@ -1057,9 +1068,57 @@ __device__ __forceinline__ void pcr_real_level(const Lane &L, const RealFactors<
     }
 }
 
+// A product that must be rounded on its own (the general path adds J_cT x_T as a finished sum; the t_local path's lone
+// product must not be fused into the addition that follows, or the two paths differ in the last bit and a reactor's
+// result would depend on its wavefront's other reactors).
+__device__ __forceinline__ double rounded(double x) { asm volatile("" : "+v"(x)); return x; }
+
+// Row-straddling zone counts, no coupling to a neighbour's temperature (t_local): the T and the pH system are
+// independent, so they go through the levels in lock step -- both systems' neighbours in one batch of exchanges (one LDS
+// round trip per level instead of two) and the level's factors fetched along with them (never more than one level of
+// factors in registers).  The arithmetic per system is that of the one-system levels.
+template <int LV, int l>
+__device__ __forceinline__ void pcr_real_pair(const Lane &L, const FStore<LV> &F, double &b0, double &b1)
+{
+    using S = FSlots<LV>;
+    if constexpr (l + 1 < LV) {
+        constexpr int st = 1 << l;
+        double lo0, hi0, lo1, hi1;
+        both<false, st>(L, b0, lo0, hi0); both<false, st>(L, b1, lo1, hi1);
+        const double a0 = F.ld(2 * l), g0 = F.ld(2 * l + 1), a1 = F.ld(S::RS + 2 * l), g1 = F.ld(S::RS + 2 * l + 1);
+        b0 = b0 - a0 * keep_m(L.m_lo[l], lo0) - g0 * keep_m(L.m_hi[l], hi0);
+        b1 = b1 - a1 * keep_m(L.m_lo[l], lo1) - g1 * keep_m(L.m_hi[l], hi1);
+        pcr_real_pair<LV, l + 1>(L, F, b0, b1);
+    } else {
+        constexpr int st = 1 << (LV - 1);
+        const double p0 = from_partner<false, st>(L, b0), p1 = from_partner<false, st>(L, b1);
+        const double f0 = F.ld(2 * (LV - 1)), f1 = F.ld(S::RS + 2 * (LV - 1));
+        b0 = b0 - f0 * p0;
+        b1 = b1 - f1 * p1;
+    }
+}
+
 template <bool ROW, int LV>
 __device__ __forceinline__ void solve_real(const Lane &L, const Jac &J, const FStore<LV> &F, double b[3], bool t_local)
 {
+#ifndef WT_NO_PAIR_REAL
+    if constexpr (!ROW && LV >= 2) {
+        if (t_local) {
+            using S = FSlots<LV>;
+            double xT = b[STT], xP = b[SPH];
+            pcr_real_pair<LV, 0>(L, F, xT, xP);
+            xT *= F.ld(2 * LV - 1); xP *= F.ld(S::RS + 2 * LV - 1);
+            RealFactors<LV> fC;
+            load_real<LV>(F, 2, fC);
+            const double tC = rounded(J.ct[1] * xT);
+            double xC = b[SCL] + tC + J.cp * xP;
+            pcr_real_level<ROW, LV, 0>(L, fC, xC);
+            xC *= fC.inv;
+            b[SPH] = xP; b[SCL] = xC; b[STT] = xT;
+            return;
+        }
+    }
+#endif
     // (many levels: a system's factors are fetched when its turn comes, or the three sets together crowd the register file)
     RealFactors<LV> fT, fP, fC;
     load_real<LV>(F, 0, fT);
@@ -1071,7 +1130,7 @@ __device__ __forceinline__ void solve_real(const Lane &L, const Jac &J, const FS
     double xP, tC;
     if (t_local) {      // (wave-uniform) no row of this wavefront couples to a neighbour's temperature: see jac_t_local
         xP = b[SPH];
-        tC = J.ct[1] * xT;
+        tC = rounded(J.ct[1] * xT);
     } else {
         const double xT_lo_r = from_lo<ROW, 1>(L, xT), xT_hi_r = from_hi<ROW, 1>(L, xT);
         const double xT_lo = keep_m(L.m_lo[0], xT_lo_r), xT_hi = keep_m(L.m_hi[0], xT_hi_r); // J.pt/ct[0,2] are 0 there
@@ -1112,35 +1171,79 @@ __device__ __forceinline__ void load_sys(const FStore<LV> &F, int k, SysFactors<
     s.cinv = {F.ld(c0 + 4 * LV - 2), F.ld(c0 + 4 * LV - 1)};
 }
 
+// one level of a real + complex pair of systems, given the (masked) neighbours' values and the level's factors
+__device__ __forceinline__ void rc_apply(double ra, double rg, cplx ca, cplx cg, double b_lo, double b_hi, cplx c_lo, cplx c_hi,
+                                         double &b, cplx &c)
+{
+    b = b - ra * b_lo - rg * b_hi;
+    // c -= ca * c_lo + cg * c_hi as eight fused multiply-adds (no separate products and subtractions)
+    double cr = c.r, ci = c.i;
+    cr = __builtin_fma(-ca.r, c_lo.r, cr); ci = __builtin_fma(-ca.r, c_lo.i, ci);
+    cr = __builtin_fma(ca.i, c_lo.i, cr);  ci = __builtin_fma(-ca.i, c_lo.r, ci);
+    cr = __builtin_fma(-cg.r, c_hi.r, cr); ci = __builtin_fma(-cg.r, c_hi.i, ci);
+    cr = __builtin_fma(cg.i, c_hi.i, cr);  ci = __builtin_fma(-cg.i, c_hi.r, ci);
+    c = {cr, ci};
+}
+// the top level: one partner, one factor
+__device__ __forceinline__ void rc_apply_top(double rf, cplx cf, double b_p, cplx c_p, double &b, cplx &c)
+{
+    b = b - rf * b_p;
+    double cr = c.r, ci = c.i;
+    cr = __builtin_fma(-cf.r, c_p.r, cr); ci = __builtin_fma(-cf.r, c_p.i, ci);
+    cr = __builtin_fma(cf.i, c_p.i, cr);  ci = __builtin_fma(-cf.i, c_p.r, ci);
+    c = {cr, ci};
+}
+template <bool ROW, int LV, int l>
+__device__ __forceinline__ void rc_neighbours(const Lane &L, double b, cplx c, double &b_lo, double &b_hi, cplx &c_lo, cplx &c_hi)
+{
+    constexpr int st = 1 << l;
+    both<ROW, st>(L, b, b_lo, b_hi); cboth<ROW, st>(L, c, c_lo, c_hi);
+    b_lo = keep_m(L.m_lo[l], b_lo); b_hi = keep_m(L.m_hi[l], b_hi);
+    c_lo = {keep_m(L.m_lo[l], c_lo.r), keep_m(L.m_lo[l], c_lo.i)};
+    c_hi = {keep_m(L.m_hi[l], c_hi.r), keep_m(L.m_hi[l], c_hi.i)};
+}
+
 template <bool ROW, int LV, int l>
 __device__ __forceinline__ void pcr_rc_level(const Lane &L, const SysFactors<LV> &s, double &b, cplx &c)
 {
     if constexpr (l + 1 < LV) {
-        constexpr int st = 1 << l;
         double b_lo, b_hi; cplx c_lo, c_hi;
-        both<ROW, st>(L, b, b_lo, b_hi); cboth<ROW, st>(L, c, c_lo, c_hi);
-        b_lo = keep_m(L.m_lo[l], b_lo); b_hi = keep_m(L.m_hi[l], b_hi);
-        c_lo = {keep_m(L.m_lo[l], c_lo.r), keep_m(L.m_lo[l], c_lo.i)};
-        c_hi = {keep_m(L.m_hi[l], c_hi.r), keep_m(L.m_hi[l], c_hi.i)};
-        b = b - s.ra[l] * b_lo - s.rg[l] * b_hi;
-        // c -= ca * c_lo + cg * c_hi as eight fused multiply-adds (no separate products and subtractions)
-        double cr = c.r, ci = c.i;
-        cr = __builtin_fma(-s.ca[l].r, c_lo.r, cr); ci = __builtin_fma(-s.ca[l].r, c_lo.i, ci);
-        cr = __builtin_fma(s.ca[l].i, c_lo.i, cr);  ci = __builtin_fma(-s.ca[l].i, c_lo.r, ci);
-        cr = __builtin_fma(-s.cg[l].r, c_hi.r, cr); ci = __builtin_fma(-s.cg[l].r, c_hi.i, ci);
-        cr = __builtin_fma(s.cg[l].i, c_hi.i, cr);  ci = __builtin_fma(-s.cg[l].i, c_hi.r, ci);
-        c = {cr, ci};
+        rc_neighbours<ROW, LV, l>(L, b, c, b_lo, b_hi, c_lo, c_hi);
+        rc_apply(s.ra[l], s.rg[l], s.ca[l], s.cg[l], b_lo, b_hi, c_lo, c_hi, b, c);
         pcr_rc_level<ROW, LV, l + 1>(L, s, b, c);
     } else {
-        // top level: one partner, one factor
         constexpr int st = 1 << (LV - 1);
         const double b_p = from_partner<ROW, st>(L, b);
         const cplx c_p = {from_partner<ROW, st>(L, c.r), from_partner<ROW, st>(L, c.i)};
-        b = b - s.rf * b_p;
-        double cr = c.r, ci = c.i;
-        cr = __builtin_fma(-s.cf.r, c_p.r, cr); ci = __builtin_fma(-s.cf.r, c_p.i, ci);
-        cr = __builtin_fma(s.cf.i, c_p.i, cr);  ci = __builtin_fma(-s.cf.i, c_p.r, ci);
-        c = {cr, ci};
+        rc_apply_top(s.rf, s.cf, b_p, c_p, b, c);
+    }
+}
+
+// T and pH systems in lock step (see pcr_real_pair)
+template <int LV, int l>
+__device__ __forceinline__ void pcr_rc_pair(const Lane &L, const FStore<LV> &F, double &b0, cplx &c0, double &b1, cplx &c1)
+{
+    using S = FSlots<LV>;
+    constexpr int r0 = 0, r1 = S::RS, q0 = S::CB, q1 = S::CB + S::CS;
+    if constexpr (l + 1 < LV) {
+        double bl0, bh0, bl1, bh1; cplx cl0, ch0, cl1, ch1;
+        rc_neighbours<false, LV, l>(L, b0, c0, bl0, bh0, cl0, ch0);
+        rc_neighbours<false, LV, l>(L, b1, c1, bl1, bh1, cl1, ch1);
+        const double ra0 = F.ld(r0 + 2 * l), rg0 = F.ld(r0 + 2 * l + 1), ra1 = F.ld(r1 + 2 * l), rg1 = F.ld(r1 + 2 * l + 1);
+        const cplx ca0 = {F.ld(q0 + 4 * l), F.ld(q0 + 4 * l + 1)}, cg0 = {F.ld(q0 + 4 * l + 2), F.ld(q0 + 4 * l + 3)};
+        const cplx ca1 = {F.ld(q1 + 4 * l), F.ld(q1 + 4 * l + 1)}, cg1 = {F.ld(q1 + 4 * l + 2), F.ld(q1 + 4 * l + 3)};
+        rc_apply(ra0, rg0, ca0, cg0, bl0, bh0, cl0, ch0, b0, c0);
+        rc_apply(ra1, rg1, ca1, cg1, bl1, bh1, cl1, ch1, b1, c1);
+        pcr_rc_pair<LV, l + 1>(L, F, b0, c0, b1, c1);
+    } else {
+        constexpr int st = 1 << (LV - 1);
+        const double p0 = from_partner<false, st>(L, b0), p1 = from_partner<false, st>(L, b1);
+        const cplx cp0 = {from_partner<false, st>(L, c0.r), from_partner<false, st>(L, c0.i)};
+        const cplx cp1 = {from_partner<false, st>(L, c1.r), from_partner<false, st>(L, c1.i)};
+        const double rf0 = F.ld(r0 + 2 * (LV - 1)), rf1 = F.ld(r1 + 2 * (LV - 1));
+        const cplx cf0 = {F.ld(q0 + 4 * (LV - 1)), F.ld(q0 + 4 * (LV - 1) + 1)}, cf1 = {F.ld(q1 + 4 * (LV - 1)), F.ld(q1 + 4 * (LV - 1) + 1)};
+        rc_apply_top(rf0, cf0, p0, cp0, b0, c0);
+        rc_apply_top(rf1, cf1, p1, cp1, b1, c1);
     }
 }
 
@@ -1152,6 +1255,26 @@ __device__ __forceinline__ void solve_rc(const Lane &L, const Jac &J, const FSto
     // of three).  Many levels (n > 8): 6 LV + 3 doubles per system -- fetched system by system, or the three sets
     // together overflow the register file into scratch.
     SysFactors<LV> sT, sP, sC;
+#ifndef WT_NO_PAIR_RC
+    if constexpr (!ROW && LV >= 2) {
+        if (t_local) {
+            using S = FSlots<LV>;
+            double xT = br[STT], xP = br[SPH]; cplx zT = {cr[STT], ci[STT]}, zP = {cr[SPH], ci[SPH]};
+            pcr_rc_pair<LV, 0>(L, F, xT, zT, xP, zP);
+            xT *= F.ld(2 * LV - 1); zT = cmul(zT, {F.ld(S::CB + 4 * LV - 2), F.ld(S::CB + 4 * LV - 1)});
+            xP *= F.ld(S::RS + 2 * LV - 1); zP = cmul(zP, {F.ld(S::CB + S::CS + 4 * LV - 2), F.ld(S::CB + S::CS + 4 * LV - 1)});
+            load_sys<LV>(F, 2, sC);
+            const double tC = rounded(J.ct[1] * xT); const cplx uC = {rounded(J.ct[1] * zT.r), rounded(J.ct[1] * zT.i)};
+            double xC = br[SCL] + tC + J.cp * xP;
+            cplx zC = {cr[SCL] + uC.r + J.cp * zP.r, ci[SCL] + uC.i + J.cp * zP.i};
+            pcr_rc_level<ROW, LV, 0>(L, sC, xC, zC);
+            xC *= sC.rinv; zC = cmul(zC, sC.cinv);
+            br[SPH] = xP; br[SCL] = xC; br[STT] = xT;
+            cr[SPH] = zP.r; ci[SPH] = zP.i; cr[SCL] = zC.r; ci[SCL] = zC.i; cr[STT] = zT.r; ci[STT] = zT.i;
+            return;
+        }
+    }
+#endif
     load_sys<LV>(F, 0, sT);
     if constexpr (LV < 4) load_sys<LV>(F, 1, sP);
     // temperature block
@@ -1162,7 +1285,7 @@ __device__ __forceinline__ void solve_rc(const Lane &L, const Jac &J, const FSto
     double xP, tC; cplx zP, uC;
     if (t_local) {      // (wave-uniform) no row of this wavefront couples to a neighbour's temperature: see jac_t_local
         xP = br[SPH]; zP = {cr[SPH], ci[SPH]};
-        tC = J.ct[1] * xT; uC = {J.ct[1] * zT.r, J.ct[1] * zT.i};
+        tC = rounded(J.ct[1] * xT); uC = {rounded(J.ct[1] * zT.r), rounded(J.ct[1] * zT.i)};
     } else {
         const double xT_lo = keep_m(L.m_lo[0], from_lo<ROW, 1>(L, xT)), xT_hi = keep_m(L.m_hi[0], from_hi<ROW, 1>(L, xT));
         const cplx zT_lo = {keep_m(L.m_lo[0], from_lo<ROW, 1>(L, zT.r)), keep_m(L.m_lo[0], from_lo<ROW, 1>(L, zT.i))};
