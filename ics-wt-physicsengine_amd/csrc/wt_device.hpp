@@ -851,17 +851,40 @@ constexpr int fstore_lds_slots(int LV)
 {
     if (LV >= 6) return fstore_total_slots(LV) - 3 * (2 * LV);                        // n > 32: three wavefronts per CU either way; registers measured faster
     const int budget = 40960;                                  // bytes per wavefront at four per CU (n > 16: less the exchange row)
-    const int fixed = (RK_UNI * rk_maxr(LV) + rk_lane_doubles(LV) + rk_maxr(LV) + 64) * 8;   // LdsMap: reactor constants, history base, reactor indices, exchange row
+    const int fixed = ((RK_UNI * rk_maxr(LV) + rk_lane_doubles(LV) + rk_maxr(LV) + 64 + 1) & ~1) * 8;   // LdsMap: reactor constants, history base, reactor indices, exchange row (F_OFF)
     const int fit = (budget - fixed) / 512;
     return fit < fstore_total_slots(LV) ? fit : fstore_total_slots(LV);
 }
+typedef double __attribute__((ext_vector_type(2))) double2v;
+typedef __attribute__((address_space(3))) double2v LdsDouble2;
 template <int LV> struct FStore {
     static constexpr int NREG = fstore_total_slots(LV) - fstore_lds_slots(LV);   // slots [0, NREG) in registers
+    static_assert(NREG % 2 == 0, "slots come in pairs");
     double reg[NREG > 0 ? NREG : 1];
-    double *base;   // this lane's LDS column: base[(slot - NREG) * 64]
+    // Slots live in LDS as PAIRS (2j, 2j + 1) -- (alpha, gamma) of a level, (re, im) of a complex factor, (top factor,
+    // 1/d) -- one 16-byte cell per pair and lane, pair-major: cell[(pair) * 64 + lane].  A pair is written and read
+    // together with one ds_write_b128 / ds_read_b128: the read costs half of a two-address ds_read2st64_b64
+    // (16 vs 32 cycles per wavefront with the CU's four wavefronts on its LDS pipe: tools/ubench/lds.hip).
+    LdsDouble2 *cell;   // this lane's column of pairs: cell[pair * 64]
     // `slot` is a compile-time constant at every call site after inlining / unrolling
-    __device__ __forceinline__ double ld(int slot) const { return (slot < NREG) ? reg[slot < NREG ? slot : 0] : base[(slot - NREG) * 64]; }
-    __device__ __forceinline__ void st(int slot, double v) { if (slot < NREG) reg[slot < NREG ? slot : 0] = v; else base[(slot - NREG) * 64] = v; }
+    __device__ __forceinline__ double ld(int slot) const
+    {
+        if (slot < NREG) return reg[slot < NREG ? slot : 0];
+        const LdsDouble *p = (const LdsDouble *)(cell + ((slot - NREG) >> 1) * 64);
+        return p[(slot - NREG) & 1];
+    }
+    __device__ __forceinline__ void ld2(int slot, double &a, double &b) const      // slot even
+    {
+        if (slot < NREG) { a = reg[slot < NREG ? slot : 0]; b = reg[slot + 1 < NREG ? slot + 1 : 0]; return; }
+        const double2v v = cell[((slot - NREG) >> 1) * 64];
+        a = v.x; b = v.y;
+    }
+    __device__ __forceinline__ void st2(int slot, double a, double b)             // slot even
+    {
+        if (slot < NREG) { reg[slot < NREG ? slot : 0] = a; reg[slot + 1 < NREG ? slot + 1 : 0] = b; return; }
+        double2v v; v.x = a; v.y = b;
+        cell[((slot - NREG) >> 1) * 64] = v;
+    }
 };
 // slot map: real system k (0..2): [k RS + 2l] = alpha_l, [+2l+1] = gamma_l for the levels l < LV-1 below the top one,
 //           [+2(LV-1)] = the top level's one factor (alpha for zones >= 2^(LV-1), gamma below: never both), [+2LV-1] = 1/d
@@ -919,7 +942,7 @@ __device__ __forceinline__ void pcr_factor_level_all(const Lane &L, double ar[3]
             dr[k] = dr[k] - al * c_lo - ga * a_hi;
             ar[k] = -al * a_lo;
             cr[k] = -ga * c_hi;
-            F.st(k * S::RS + 2 * l, al); F.st(k * S::RS + 2 * l + 1, ga);
+            F.st2(k * S::RS + 2 * l, al, ga);
             // complex shift: alpha = a / d_lo, gamma = c / d_hi with real a, c
             const cplx cid = cinv(dc[k]);
             const cplx i_lo = cfrom_lo<ROW, s>(L, cid), i_hi = cfrom_hi<ROW, s>(L, cid);
@@ -934,7 +957,7 @@ __device__ __forceinline__ void pcr_factor_level_all(const Lane &L, double ar[3]
             ac[k] = {-(cal.r * a_lo), -(cal.i * a_lo)};
             cc[k] = {-(cga.r * c_hi), -(cga.i * c_hi)};
             const int c0s = S::CB + k * S::CS + 4 * l;
-            F.st(c0s, cal.r); F.st(c0s + 1, cal.i); F.st(c0s + 2, cga.r); F.st(c0s + 3, cga.i);
+            F.st2(c0s, cal.r, cal.i); F.st2(c0s + 2, cga.r, cga.i);
         }
         if constexpr (l + 2 < LV) pcr_factor_level_all<ROW, LV, l + 1>(L, ar, dr, cr, ac, dc, cc, F);
         return;
@@ -953,7 +976,7 @@ __device__ __forceinline__ void pcr_factor_level_all(const Lane &L, double ar[3]
         dr[k] = dr[k] - al * keep_m(L.m_lo[l], c_lo) - ga * keep_m(L.m_hi[l], a_hi);
         ar[k] = -al * keep_m(L.m_lo[l], a_lo);
         cr[k] = -ga * keep_m(L.m_hi[l], c_hi);
-        F.st(k * S::RS + 2 * l, al); F.st(k * S::RS + 2 * l + 1, ga);
+        F.st2(k * S::RS + 2 * l, al, ga);
     }
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -980,7 +1003,7 @@ __device__ __forceinline__ void pcr_factor_level_all(const Lane &L, double ar[3]
         ac[k] = {-na.r, -na.i};
         cc[k] = {-nc.r, -nc.i};
         const int c0 = S::CB + k * S::CS + 4 * l;
-        F.st(c0, al.r); F.st(c0 + 1, al.i); F.st(c0 + 2, ga.r); F.st(c0 + 3, ga.i);
+        F.st2(c0, al.r, al.i); F.st2(c0 + 2, ga.r, ga.i);
     }
     if constexpr (l + 2 < LV) pcr_factor_level_all<ROW, LV, l + 1>(L, ar, dr, cr, ac, dc, cc, F);
 }
@@ -990,7 +1013,7 @@ __device__ __forceinline__ void pcr_factor_level_all(const Lane &L, double ar[3]
 // back.  One factor and a third of the cross-lane moves of a regular level; the same bits.
 template <bool ROW, int LV>
 __device__ __forceinline__ void pcr_factor_top_all(const Lane &L, double ar[3], double dr[3], double cr[3],
-                                                   cplx ac[3], cplx dc[3], cplx cc[3], FStore<LV> &F)
+                                                   cplx ac[3], cplx dc[3], cplx cc[3], FStore<LV> &F, double ftop[3])
 {
     using S = FSlots<LV>;
     constexpr int s = 1 << (LV - 1);
@@ -1000,7 +1023,7 @@ __device__ __forceinline__ void pcr_factor_top_all(const Lane &L, double ar[3], 
         const double p_id = from_partner<ROW, s>(L, id), p_w = from_partner<ROW, s>(L, w);
         const double f = w * p_id;
         dr[k] = dr[k] - f * p_w;
-        F.st(k * S::RS + 2 * (LV - 1), f);
+        ftop[k] = f;                                  // stored with 1/d, its pair (factorize)
     }
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -1013,7 +1036,7 @@ __device__ __forceinline__ void pcr_factor_top_all(const Lane &L, double ar[3], 
         dre = __builtin_fma(f.i, p_w.i, dre);  dim = __builtin_fma(-f.i, p_w.r, dim);
         dc[k] = {dre, dim};
         const int c0 = S::CB + k * S::CS + 4 * (LV - 1);
-        F.st(c0, f.r); F.st(c0 + 1, f.i);
+        F.st2(c0, f.r, f.i);
     }
 }
 
@@ -1032,12 +1055,13 @@ __device__ __forceinline__ void factorize(const Lane &L, const Jac &J, double h,
     cplx dc[3] = {{mcr - J.tt[1], mci}, {mcr - J.pp[1], mci}, {mcr - J.cc[1], mci}};
     cplx cc[3] = {{cr[0], 0.0}, {cr[1], 0.0}, {cr[2], 0.0}};
     if constexpr (LV > 1) pcr_factor_level_all<ROW, LV, 0>(L, ar, dr, cr, ac, dc, cc, F);
-    pcr_factor_top_all<ROW, LV>(L, ar, dr, cr, ac, dc, cc, F);
+    double ftop[3];
+    pcr_factor_top_all<ROW, LV>(L, ar, dr, cr, ac, dc, cc, F, ftop);
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        F.st(k * S::RS + 2 * LV - 1, rcp(dr[k]));
+        F.st2(k * S::RS + 2 * (LV - 1), ftop[k], rcp(dr[k]));
         const cplx inv = cinv(dc[k]);
-        F.st(S::CB + k * S::CS + 4 * LV - 2, inv.r); F.st(S::CB + k * S::CS + 4 * LV - 1, inv.i);
+        F.st2(S::CB + k * S::CS + 4 * LV - 2, inv.r, inv.i);
     }
 }
 
@@ -1050,8 +1074,8 @@ __device__ __forceinline__ void load_real(const FStore<LV> &F, int k, RealFactor
 {
     using S = FSlots<LV>;
 #pragma unroll
-    for (int l = 0; l + 1 < LV; ++l) { s.a[l] = F.ld(k * S::RS + 2 * l); s.g[l] = F.ld(k * S::RS + 2 * l + 1); }
-    s.f = F.ld(k * S::RS + 2 * (LV - 1)); s.inv = F.ld(k * S::RS + 2 * LV - 1);
+    for (int l = 0; l + 1 < LV; ++l) F.ld2(k * S::RS + 2 * l, s.a[l], s.g[l]);
+    F.ld2(k * S::RS + 2 * (LV - 1), s.f, s.inv);
 }
 
 template <bool ROW, int LV, int l>
@@ -1085,7 +1109,8 @@ __device__ __forceinline__ void pcr_real_pair(const Lane &L, const FStore<LV> &F
         constexpr int st = 1 << l;
         double lo0, hi0, lo1, hi1;
         both<false, st>(L, b0, lo0, hi0); both<false, st>(L, b1, lo1, hi1);
-        const double a0 = F.ld(2 * l), g0 = F.ld(2 * l + 1), a1 = F.ld(S::RS + 2 * l), g1 = F.ld(S::RS + 2 * l + 1);
+        double a0, g0, a1, g1;
+        F.ld2(2 * l, a0, g0); F.ld2(S::RS + 2 * l, a1, g1);
         b0 = b0 - a0 * keep_m(L.m_lo[l], lo0) - g0 * keep_m(L.m_hi[l], hi0);
         b1 = b1 - a1 * keep_m(L.m_lo[l], lo1) - g1 * keep_m(L.m_hi[l], hi1);
         pcr_real_pair<LV, l + 1>(L, F, b0, b1);
@@ -1162,13 +1187,13 @@ __device__ __forceinline__ void load_sys(const FStore<LV> &F, int k, SysFactors<
     const int r0 = k * S::RS, c0 = S::CB + k * S::CS;
 #pragma unroll
     for (int l = 0; l + 1 < LV; ++l) {
-        s.ra[l] = F.ld(r0 + 2 * l); s.rg[l] = F.ld(r0 + 2 * l + 1);
-        s.ca[l] = {F.ld(c0 + 4 * l), F.ld(c0 + 4 * l + 1)};
-        s.cg[l] = {F.ld(c0 + 4 * l + 2), F.ld(c0 + 4 * l + 3)};
+        F.ld2(r0 + 2 * l, s.ra[l], s.rg[l]);
+        F.ld2(c0 + 4 * l, s.ca[l].r, s.ca[l].i);
+        F.ld2(c0 + 4 * l + 2, s.cg[l].r, s.cg[l].i);
     }
-    s.rf = F.ld(r0 + 2 * (LV - 1)); s.rinv = F.ld(r0 + 2 * LV - 1);
-    s.cf = {F.ld(c0 + 4 * (LV - 1)), F.ld(c0 + 4 * (LV - 1) + 1)};
-    s.cinv = {F.ld(c0 + 4 * LV - 2), F.ld(c0 + 4 * LV - 1)};
+    F.ld2(r0 + 2 * (LV - 1), s.rf, s.rinv);
+    F.ld2(c0 + 4 * (LV - 1), s.cf.r, s.cf.i);
+    F.ld2(c0 + 4 * LV - 2, s.cinv.r, s.cinv.i);
 }
 
 // one level of a real + complex pair of systems, given the (masked) neighbours' values and the level's factors
@@ -1229,9 +1254,10 @@ __device__ __forceinline__ void pcr_rc_pair(const Lane &L, const FStore<LV> &F, 
         double bl0, bh0, bl1, bh1; cplx cl0, ch0, cl1, ch1;
         rc_neighbours<false, LV, l>(L, b0, c0, bl0, bh0, cl0, ch0);
         rc_neighbours<false, LV, l>(L, b1, c1, bl1, bh1, cl1, ch1);
-        const double ra0 = F.ld(r0 + 2 * l), rg0 = F.ld(r0 + 2 * l + 1), ra1 = F.ld(r1 + 2 * l), rg1 = F.ld(r1 + 2 * l + 1);
-        const cplx ca0 = {F.ld(q0 + 4 * l), F.ld(q0 + 4 * l + 1)}, cg0 = {F.ld(q0 + 4 * l + 2), F.ld(q0 + 4 * l + 3)};
-        const cplx ca1 = {F.ld(q1 + 4 * l), F.ld(q1 + 4 * l + 1)}, cg1 = {F.ld(q1 + 4 * l + 2), F.ld(q1 + 4 * l + 3)};
+        double ra0, rg0, ra1, rg1; cplx ca0, cg0, ca1, cg1;
+        F.ld2(r0 + 2 * l, ra0, rg0); F.ld2(r1 + 2 * l, ra1, rg1);
+        F.ld2(q0 + 4 * l, ca0.r, ca0.i); F.ld2(q0 + 4 * l + 2, cg0.r, cg0.i);
+        F.ld2(q1 + 4 * l, ca1.r, ca1.i); F.ld2(q1 + 4 * l + 2, cg1.r, cg1.i);
         rc_apply(ra0, rg0, ca0, cg0, bl0, bh0, cl0, ch0, b0, c0);
         rc_apply(ra1, rg1, ca1, cg1, bl1, bh1, cl1, ch1, b1, c1);
         pcr_rc_pair<LV, l + 1>(L, F, b0, c0, b1, c1);
@@ -1241,7 +1267,8 @@ __device__ __forceinline__ void pcr_rc_pair(const Lane &L, const FStore<LV> &F, 
         const cplx cp0 = {from_partner<false, st>(L, c0.r), from_partner<false, st>(L, c0.i)};
         const cplx cp1 = {from_partner<false, st>(L, c1.r), from_partner<false, st>(L, c1.i)};
         const double rf0 = F.ld(r0 + 2 * (LV - 1)), rf1 = F.ld(r1 + 2 * (LV - 1));
-        const cplx cf0 = {F.ld(q0 + 4 * (LV - 1)), F.ld(q0 + 4 * (LV - 1) + 1)}, cf1 = {F.ld(q1 + 4 * (LV - 1)), F.ld(q1 + 4 * (LV - 1) + 1)};
+        cplx cf0, cf1;
+        F.ld2(q0 + 4 * (LV - 1), cf0.r, cf0.i); F.ld2(q1 + 4 * (LV - 1), cf1.r, cf1.i);
         rc_apply_top(rf0, cf0, p0, cp0, b0, c0);
         rc_apply_top(rf1, cf1, p1, cp1, b1, c1);
     }
@@ -1624,7 +1651,7 @@ template <int LV> struct LdsMap {
     // the factor store.  A lane whose neighbour lies outside the wavefront reads up to 2^(LV-2) cells beyond either
     // end -- constants or factors of this same allocation, masked by the caller like every out-of-segment value.
     static constexpr int X_OFF = RK_DOUBLES + HIST_DOUBLES, X_DOUBLES = 64;
-    static constexpr int F_OFF = X_OFF + X_DOUBLES;
+    static constexpr int F_OFF = (X_OFF + X_DOUBLES + 1) & ~1;       // 16-byte aligned: the factor store's cells are pairs
     static constexpr int TOTAL = F_OFF + TAIL_DOUBLES;
     static_assert(X_OFF >= (LV >= 2 ? (1 << (LV - 2)) : 0), "reads below the exchange row must stay inside the allocation");
 };
@@ -1823,7 +1850,7 @@ __device__ __forceinline__ void run_item(ArgPtr pa, const Lane &L, double *lds, 
             double Q[3][3], y_old[3] = {0, 0, 0};     // dense output of the last accepted step
             Jac J;
             FStore<LV> F;
-            F.base = lds_factors + lane;
+            F.cell = (LdsDouble2 *)lds_factors + lane;
             uint32_t fl = 1u << 4;                    // current_jac = true
             Flag have_fac{fl, 1u << 0}, have_old{fl, 1u << 1}, have_old_l{fl, 1u << 2}, have_sol{fl, 1u << 3}, current_jac{fl, 1u << 4},
                  have_lu{fl, 1u << 5}, rejected{fl, 1u << 6}, keep_h{fl, 1u << 7}, have_norm_old{fl, 1u << 8}, have_rate{fl, 1u << 9},
@@ -2330,7 +2357,7 @@ template <int LV, bool ROW>
 __global__ __launch_bounds__(64) void step_kernel(const StepArgs a_unused)
 {
     (void)a_unused;   // never read directly: every section fetches what it needs through `pa` (see fresh())
-    __shared__ double lds[LdsMap<LV>::TOTAL];
+    __shared__ __attribute__((aligned(16))) double lds[LdsMap<LV>::TOTAL];
     // the by-value argument block sits at offset 0 of the kernel-argument segment
     const ArgPtr pa = (ArgPtr)__builtin_amdgcn_kernarg_segment_ptr();
     Lane L;

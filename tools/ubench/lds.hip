@@ -33,6 +33,10 @@ template <int MODE> __global__ __launch_bounds__(64) void k(long long *out, int 
         if constexpr (MODE == 7) { asm volatile(REP16("ds_read2st64_b64 %0, %1 offset0:1 offset1:2\n") "s_waitcnt lgkmcnt(0)" : "=&v"(r) : "v"(a8) : "memory"); }
         if constexpr (MODE == 9) { asm volatile(REP16("v_fma_f64 %0, %1, %1, %1\n") : "=&v"(e) : "v"(m)); }
         if constexpr (MODE == 10) { asm volatile(REP16("v_mov_b32_dpp %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n") : "=&v"(y) : "v"(x)); }
+        if constexpr (MODE == 11) { asm volatile(REP16("ds_read2_b64 %0, %1 offset0:0 offset1:1\n") "s_waitcnt lgkmcnt(0)" : "=&v"(r) : "v"(a16) : "memory"); }
+        if constexpr (MODE == 12) { asm volatile(REP16("ds_write2st64_b64 %0, %1, %2 offset0:1 offset1:2\n") "s_waitcnt lgkmcnt(0)" :: "v"(a8), "v"(m), "v"(d) : "memory"); }
+        if constexpr (MODE == 13) { asm volatile(REP16("ds_write_b128 %0, %1\n") "s_waitcnt lgkmcnt(0)" :: "v"(a16), "v"(q) : "memory"); }
+        if constexpr (MODE == 14) { asm volatile(REP16("ds_write_b64 %0, %1\n") "s_waitcnt lgkmcnt(0)" :: "v"(a8), "v"(m) : "memory"); }
         if constexpr (MODE == 8) { asm volatile(REP16("ds_bpermute_b32 %0, %2, %3\n v_fma_f64 %1, %4, %4, %4\n") "s_waitcnt lgkmcnt(0)" : "=&v"(y), "=&v"(e) : "v"(bp), "v"(x), "v"(m) : "memory"); }
     }
     long long t1 = __builtin_amdgcn_s_memtime();
@@ -62,6 +66,10 @@ int main()
     run<2>("16 ds_read_b64, one wait", blocks);
     run<3>("16 ds_read_b128, one wait", blocks);
     run<7>("16 ds_read2st64_b64, one wait", blocks);
+    run<11>("16 ds_read2_b64 (adjacent doubles), one wait", blocks);
+    run<12>("16 ds_write2st64_b64, one wait", blocks);
+    run<13>("16 ds_write_b128, one wait", blocks);
+    run<14>("16 ds_write_b64, one wait", blocks);
     run<4>("16 x (ds_write_b64 + 2 ds_read_b64 of the neighbours), one wait", blocks);
     run<5>("16 x (ds_write_b128 + 2 ds_read_b128 of the neighbours), one wait", blocks);
     run<6>("16 v_mov_b32_dpp wave_shr:1", blocks);
