@@ -252,3 +252,34 @@ def test_build_staleness_list_matches_the_includes():
         todo += [m for m in re.findall(r'#include "([^"/]+)"', text) if os.path.exists(os.path.join(native.CSRC, m))]
     assert seen == set(native.BUILD_SOURCES)
     assert not [f for f in os.listdir(native.CSRC) if f.endswith((".hpp", ".hip")) and f not in seen], "dead source in csrc/"
+
+
+def test_step_kernels_fit_the_register_file_and_four_wavefronts_per_cu(tmp_path):
+    """Code-object metadata of the built library (what the loader sees): every step kernel up to 32 zones (LV <= 5,
+    BASELINE config 3's n = 20 among them) runs without scratch memory, and its LDS leaves room for four wavefronts per
+    CU (160 KiB / 4).  A register or LDS regression shows here, on the CPU, before it shows as a slower bench line."""
+    import importlib, shutil, subprocess
+    native = importlib.import_module("ics-wt-physicsengine_amd.core._native")
+    llvm = "/opt/rocm/lib/llvm/bin"
+    if not all(os.path.exists(os.path.join(llvm, t)) for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-readelf")):
+        pytest.skip("ROCm LLVM tools not installed")
+    fat, dev = str(tmp_path / "fat.bin"), str(tmp_path / "dev.co")
+    subprocess.run([f"{llvm}/llvm-objcopy", f"--dump-section=.hip_fatbin={fat}", os.path.join(native.CSRC, "libwtphys.so")], check=True)
+    subprocess.run([f"{llvm}/clang-offload-bundler", "--type=o", "--unbundle", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
+                    f"--input={fat}", f"--output={dev}"], check=True)
+    notes = subprocess.run([f"{llvm}/llvm-readelf", "--notes", dev], check=True, capture_output=True, text=True).stdout
+    seen = {}
+    for block in notes.split("\n  - .agpr_count:")[1:]:
+        name = re.search(r"\.name:\s+(\S+)", block).group(1)
+        m = re.search(r"step_kernelILi(\d)ELb(\d)", name)
+        if not m:
+            continue
+        get = lambda f: int(re.search(re.escape(f) + r":\s+(\d+)", block).group(1))
+        seen[(int(m.group(1)), bool(int(m.group(2))))] = (get(".private_segment_fixed_size"), get(".group_segment_fixed_size"),
+                                                          get(".vgpr_count"))
+    assert {(1, True), (2, True), (3, True), (4, True), (2, False), (3, False), (4, False), (5, False), (6, False)} <= set(seen)
+    for (lv, row), (scratch, lds, regs) in seen.items():
+        assert regs <= 512
+        if lv <= 5:
+            assert scratch == 0, (lv, row, scratch)
+            assert lds <= 40960, (lv, row, lds)
