@@ -1126,7 +1126,6 @@ __device__ __forceinline__ void pcr_real_pair(const Lane &L, const FStore<LV> &F
 template <bool ROW, int LV>
 __device__ __forceinline__ void solve_real(const Lane &L, const Jac &J, const FStore<LV> &F, double b[3], bool t_local)
 {
-#ifndef WT_NO_PAIR_REAL
     if constexpr (!ROW && LV >= 2) {
         if (t_local) {
             using S = FSlots<LV>;
@@ -1143,7 +1142,6 @@ __device__ __forceinline__ void solve_real(const Lane &L, const Jac &J, const FS
             return;
         }
     }
-#endif
     // (many levels: a system's factors are fetched when its turn comes, or the three sets together crowd the register file)
     RealFactors<LV> fT, fP, fC;
     load_real<LV>(F, 0, fT);
@@ -1282,7 +1280,6 @@ __device__ __forceinline__ void solve_rc(const Lane &L, const Jac &J, const FSto
     // of three).  Many levels (n > 8): 6 LV + 3 doubles per system -- fetched system by system, or the three sets
     // together overflow the register file into scratch.
     SysFactors<LV> sT, sP, sC;
-#ifndef WT_NO_PAIR_RC
     if constexpr (!ROW && LV >= 2) {
         if (t_local) {
             using S = FSlots<LV>;
@@ -1301,7 +1298,6 @@ __device__ __forceinline__ void solve_rc(const Lane &L, const Jac &J, const FSto
             return;
         }
     }
-#endif
     load_sys<LV>(F, 0, sT);
     if constexpr (LV < 4) load_sys<LV>(F, 1, sP);
     // temperature block
