@@ -281,6 +281,7 @@ struct StepArgs {
     int first_step;   // index of this launch's first step within the wt_ensemble_step call (PLC scan phase)
     int call_steps;   // outer steps of the whole wt_ensemble_step call
     int step_limit;   // give up an outer step after this many step attempts (0 = never, as the reference)
+    int dense_coupling;   // developer knob: treat every Jacobian as coupling rows to neighbours' temperatures (general solve path)
     // Work queue (nullptr: stream schedule -- workgroup b advances the wavefront-group r0 / R + b by n_steps).
     // q_ctrl: Q_AVAIL, Q_HEAD, Q_TAIL, Q_ERROR; q_slots[q_cap]: (ticket + 1) << 32 | group; q_next[group]: next step.
     int32_t *q_ctrl; unsigned long long *q_slots; int32_t *q_next;
@@ -2192,7 +2193,7 @@ __device__ __forceinline__ void run_item(ArgPtr pa, const Lane &L, double *lds, 
                     asm volatile("" ::: "memory");               // a fresh fetch: do not keep the constants live across the epilogue
                     num_jac<ROW>(L, ks, [&]() { return &fresh(pa)->kt; }, yc, f, fac, hf, J, jbad, jval); cnt_s.njev++;
                     have_fac = hf;
-                    j_dense = jac_t_dense(J);
+                    j_dense = jac_t_dense(J) || fresh(pa)->dense_coupling != 0;
                     need_jac = false;
                     if (WT_RARE(seg_any(L, jbad))) {
                         if (jbad && !bad) { badstage = 4; badval = jval; }

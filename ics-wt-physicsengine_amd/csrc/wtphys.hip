@@ -70,8 +70,9 @@ struct wt_ensemble {
     // schedule, kept for comparison): n_sub contiguous reactor ranges on their own HIP streams, launches of
     // at most chunk_steps outer steps.  chunk_steps is also the PLC scan interval.
     // developer knobs (tools/), read from the environment once at creation: WT_Q_ITEM (outer steps per work item),
-    // WT_PLACE_MIN (history before a re-deal), WT_Q_TICKETS (forces the launch split), WT_FULL_WAVES
-    int knob_item = 0; int64_t knob_place_min = 0, knob_tickets = 0;
+    // WT_PLACE_MIN (history before a re-deal), WT_Q_TICKETS (forces the launch split), WT_FULL_WAVES,
+    // WT_DENSE_COUPLING (every solve takes the general path: the test that the fast paths give the same bits)
+    int knob_item = 0; int64_t knob_place_min = 0, knob_tickets = 0; int knob_dense = 0;
     // sticky record of a launch that did not advance every group (device word + pinned host mirror)
     int32_t *q_sticky = nullptr;   // device view of err_host (host-coherent pinned memory: the check kernel writes it in place)
     // one contiguous snapshot of a small ensemble: packed on the device, one copy into pinned memory
@@ -112,7 +113,7 @@ wt::StepArgs make_args(const wt_ensemble *h, double dt, int n_steps, int first_s
     a.dH = h->dH; a.dRho = h->dRho; a.dK = h->dK;
     a.status = h->status; a.stats = h->stats; a.wave_diag = h->wave_diag; a.bad_T = h->bad_T;
     a.perm = h->perm; a.cost = (h->placement == WT_PLACE_ADAPTIVE) ? h->cost : nullptr;
-    a.dt = dt; a.n_steps = n_steps; a.first_step = first_step; a.call_steps = call_steps; a.step_limit = h->step_limit;
+    a.dt = dt; a.n_steps = n_steps; a.first_step = first_step; a.call_steps = call_steps; a.step_limit = h->step_limit; a.dense_coupling = h->knob_dense;
     a.q_ctrl = nullptr; a.q_slots = nullptr; a.q_next = nullptr; a.q_cap = 0; a.item_steps = n_steps; a.n_groups = (int)h->n_groups;
     a.trace = h->trace; a.trace_cap = h->trace_cap;
     a.kt = wt::default_ktab(); a.rt = wt::default_rtab();
@@ -332,6 +333,7 @@ int wt_ensemble_create(int64_t n_reactors, int n_zones, int device, const double
     if (const char *e = getenv("WT_Q_ITEM")) h->knob_item = atoi(e);
     if (const char *e = getenv("WT_PLACE_MIN")) h->knob_place_min = atoll(e);
     if (const char *e = getenv("WT_Q_TICKETS")) h->knob_tickets = atoll(e);
+    if (const char *e = getenv("WT_DENSE_COUPLING")) h->knob_dense = atoi(e) != 0;
 #undef ALLOC
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { cleanup(); return fail(WT_E_HIP, "hipStreamCreate failed"); }
     h->own_stream = true;

@@ -230,6 +230,30 @@ def test_placement_changes_no_bit(gpu, wt, n):
         assert np.array_equal(a_, b_, equal_nan=True)
 
 
+@pytest.mark.parametrize("n", [5, 8, 12, 20, 40])
+def test_solve_fast_paths_change_no_bit(gpu, wt, monkeypatch, n):
+    """A wavefront none of whose Jacobians couples a row to a neighbour's temperature skips those terms in every solve,
+    and at the row-straddling zone counts solves the T and the pH system in lock step (wt_device.hpp: jac_t_dense,
+    pcr_rc_pair).  Which path a reactor takes depends on the other reactors of its wavefront, so the paths must agree
+    bit for bit: WT_DENSE_COUPLING sends every solve down the general path, and state, status and solver counters are
+    those of the default run."""
+    N = 1500 if n <= 20 else 300
+    cols, bc = wt.make_ensemble(N, seed=77)
+    def run(dense):
+        if dense:
+            monkeypatch.setenv("WT_DENSE_COUPLING", "1")
+        else:
+            monkeypatch.delenv("WT_DENSE_COUPLING", raising=False)
+        ens = wt.ReactorEnsemble(cols, n_zones=n); ens.set_boundary(bc)       # (the knob is read at creation)
+        es = ens.step(1.0, n_steps=25)
+        out = (es.pH, es.chlorine, es.temperature, es.time, es.status, ens.solver_stats())
+        ens.close()
+        return out
+    fast, general = run(False), run(True)
+    for a, b in zip(fast, general):
+        assert np.array_equal(a, b, equal_nan=True)
+
+
 def test_very_long_calls_are_split_without_a_trace(gpu, wt, monkeypatch):
     """The queue's tickets are 32-bit: a call that would need more than 2^30 of them is cut into several launches
     (wtphys.hip).  With the ticket budget turned down (WT_Q_TICKETS, test knob, read when the ensemble is created) a
