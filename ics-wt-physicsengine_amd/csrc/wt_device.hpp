@@ -108,7 +108,8 @@ struct alignas(64) KTab {
     double log2e, ln2_hi, ln2_lo, e_hi, e_lo;                        // exp argument reduction and range
     double k_arr, inv_tref, c27315, c1em4;                           // Arrhenius (thermodynamics.py:160-193)
     double rho_max, rho_an, rho20, rho_sl, c20, c8, c100;            // density branches (spatial.py:177-189), T range
-    double pad_t[6];
+    double dense_bias;                                               // developer knob WT_DENSE_COUPLING: 1.0 = every Jacobian counts as coupling rows to neighbours' T
+    double pad_t[5];
 };
 static_assert(sizeof(KTab) == 56 * 8, "KTab layout");
 
@@ -132,7 +133,7 @@ __host__ __device__ constexpr KTab default_ktab()
 
 // the constants a section works with, as plain doubles (SGPR pairs after the loads below)
 struct KP { double c[10], log2_10, lg2_hi, lg2_lo, ln10_hi, ln10_lo, t_hi, t_lo, c2303, ln10, c002; };
-struct KT { double c[10], log2e, ln2_hi, ln2_lo, e_hi, e_lo, k_arr, inv_tref, c27315, c1em4, rho_max, rho_an, rho20, rho_sl, c20, c8, c100; };
+struct KT { double c[10], log2e, ln2_hi, ln2_lo, e_hi, e_lo, k_arr, inv_tref, c27315, c1em4, rho_max, rho_an, rho20, rho_sl, c20, c8, c100, dense_bias; };
 
 __host__ __device__ constexpr KP kp_of(const KTab &t)
 {
@@ -148,7 +149,7 @@ __host__ __device__ constexpr KT kt_of(const KTab &t)
     for (int i = 0; i < 10; ++i) k.c[i] = t.tc[i];
     k.log2e = t.log2e; k.ln2_hi = t.ln2_hi; k.ln2_lo = t.ln2_lo; k.e_hi = t.e_hi; k.e_lo = t.e_lo;
     k.k_arr = t.k_arr; k.inv_tref = t.inv_tref; k.c27315 = t.c27315; k.c1em4 = t.c1em4;
-    k.rho_max = t.rho_max; k.rho_an = t.rho_an; k.rho20 = t.rho20; k.rho_sl = t.rho_sl; k.c20 = t.c20; k.c8 = t.c8; k.c100 = t.c100;
+    k.rho_max = t.rho_max; k.rho_an = t.rho_an; k.rho20 = t.rho20; k.rho_sl = t.rho_sl; k.c20 = t.c20; k.c8 = t.c8; k.c100 = t.c100; k.dense_bias = t.dense_bias;
     return k;
 }
 
@@ -176,7 +177,7 @@ __device__ __forceinline__ KT load_kt(const __attribute__((address_space(4))) KT
     k.c[8] = b[0]; k.c[9] = b[1];
     k.log2e = b[2]; k.ln2_hi = b[3]; k.ln2_lo = b[4]; k.e_hi = b[5]; k.e_lo = b[6]; k.k_arr = b[7];
     k.inv_tref = c[0]; k.c27315 = c[1]; k.c1em4 = c[2]; k.rho_max = c[3]; k.rho_an = c[4]; k.rho20 = c[5]; k.rho_sl = c[6]; k.c20 = c[7];
-    k.c8 = d[0]; k.c100 = d[1];
+    k.c8 = d[0]; k.c100 = d[1]; k.dense_bias = d[2];
     return k;
 }
 
@@ -281,7 +282,6 @@ struct StepArgs {
     int first_step;   // index of this launch's first step within the wt_ensemble_step call (PLC scan phase)
     int call_steps;   // outer steps of the whole wt_ensemble_step call
     int step_limit;   // give up an outer step after this many step attempts (0 = never, as the reference)
-    int dense_coupling;   // developer knob: treat every Jacobian as coupling rows to neighbours' temperatures (general solve path)
     // Work queue (nullptr: stream schedule -- workgroup b advances the wavefront-group r0 / R + b by n_steps).
     // q_ctrl: Q_AVAIL, Q_HEAD, Q_TAIL, Q_ERROR; q_slots[q_cap]: (ticket + 1) << 32 | group; q_next[group]: next step.
     int32_t *q_ctrl; unsigned long long *q_slots; int32_t *q_next;
@@ -1509,7 +1509,7 @@ __device__ __forceinline__ void num_jac_species(const Lane &L, const KC &kc, con
 // KTP: pointer to the constant table (kernel-argument segment in the step kernel).
 template <bool ROW, class KTP>
 __device__ __forceinline__ void num_jac(const Lane &L, const RKStore &ks, KTP ktab, const double y[3], const double f[3],
-                                        double fac[3], bool &have_fac, Jac &J, bool &bad, double &badval)
+                                        double fac[3], bool &have_fac, Jac &J, bool &bad, double &badval, bool &t_dense)
 {
     if (!have_fac) { fac[0] = fac[1] = fac[2] = rc::NJ_F0; have_fac = true; }
     FdCols cols;
@@ -1543,6 +1543,7 @@ __device__ __forceinline__ void num_jac(const Lane &L, const RKStore &ks, KTP kt
         num_jac_species<ROW, STT>(L, ct, k, y, f, b, nb, fac[STT], cols, bad, badval);
 #pragma unroll
         for (int r = 0; r < 3; ++r) { J.tt[r] = cols.D[STT][r]; J.pt[r] = cols.D[SPH][r]; J.ct[r] = cols.D[SCL][r]; }
+        t_dense = jac_t_dense(J) || (ct.dense_bias != 0.0);
     }
 }
 
@@ -2189,11 +2190,11 @@ __device__ __forceinline__ void run_item(ArgPtr pa, const Lane &L, double *lds, 
                 if (__ballot(need_jac) != 0ull) WT_COUNT(diag_jac);
 #endif
                 if (need_jac) {
-                    bool jbad = false, hf = have_fac; double jval = 0;
+                    bool jbad = false, hf = have_fac, jd = false; double jval = 0;
                     asm volatile("" ::: "memory");               // a fresh fetch: do not keep the constants live across the epilogue
-                    num_jac<ROW>(L, ks, [&]() { return &fresh(pa)->kt; }, yc, f, fac, hf, J, jbad, jval); cnt_s.njev++;
+                    num_jac<ROW>(L, ks, [&]() { return &fresh(pa)->kt; }, yc, f, fac, hf, J, jbad, jval, jd); cnt_s.njev++;
                     have_fac = hf;
-                    j_dense = jac_t_dense(J) || fresh(pa)->dense_coupling != 0;
+                    j_dense = jd;
                     need_jac = false;
                     if (WT_RARE(seg_any(L, jbad))) {
                         if (jbad && !bad) { badstage = 4; badval = jval; }

@@ -113,10 +113,11 @@ wt::StepArgs make_args(const wt_ensemble *h, double dt, int n_steps, int first_s
     a.dH = h->dH; a.dRho = h->dRho; a.dK = h->dK;
     a.status = h->status; a.stats = h->stats; a.wave_diag = h->wave_diag; a.bad_T = h->bad_T;
     a.perm = h->perm; a.cost = (h->placement == WT_PLACE_ADAPTIVE) ? h->cost : nullptr;
-    a.dt = dt; a.n_steps = n_steps; a.first_step = first_step; a.call_steps = call_steps; a.step_limit = h->step_limit; a.dense_coupling = h->knob_dense;
+    a.dt = dt; a.n_steps = n_steps; a.first_step = first_step; a.call_steps = call_steps; a.step_limit = h->step_limit;
     a.q_ctrl = nullptr; a.q_slots = nullptr; a.q_next = nullptr; a.q_cap = 0; a.item_steps = n_steps; a.n_groups = (int)h->n_groups;
     a.trace = h->trace; a.trace_cap = h->trace_cap;
     a.kt = wt::default_ktab(); a.rt = wt::default_rtab();
+    a.kt.dense_bias = h->knob_dense ? 1.0 : 0.0;
     wts::SuiteArgs &s = a.sens;
     memset(&s, 0, sizeof s);
     s.on = h->sensors_on ? 1 : 0; s.plc_on = h->plc_on ? 1 : 0; s.scan_every = scan_every > 0 ? scan_every : 1;
