@@ -850,7 +850,7 @@ __device__ __forceinline__ bool jac_t_dense(const Jac &J)
 constexpr int fstore_total_slots(int LV) { return 3 * (2 * LV) + 3 * (4 * LV); }
 constexpr int fstore_lds_slots(int LV)
 {
-    if (LV >= 6) return fstore_total_slots(LV) - 3 * (2 * LV);                        // n > 32: three wavefronts per CU either way; registers measured faster
+    if (LV >= 6) return fstore_total_slots(LV) - 3 * (2 * LV);                        // n > 32: the real-shift factors in registers keep four wavefronts per CU (all in LDS: three, scratch-free, 0.55x)
     const int budget = 40960;                                  // bytes per wavefront at four per CU (n > 16: less the exchange row)
     const int fixed = ((RK_UNI * rk_maxr(LV) + rk_lane_doubles(LV) + rk_maxr(LV) + 64 + 1) & ~1) * 8;   // LdsMap: reactor constants, history base, reactor indices, exchange row (F_OFF)
     const int fit = (budget - fixed) / 512;
