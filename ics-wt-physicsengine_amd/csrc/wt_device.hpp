@@ -2011,21 +2011,25 @@ __device__ __forceinline__ void run_item(ArgPtr pa, const Lane &L, double *lds, 
                 // f(y) of a just-accepted step rides along with the next attempt's first Newton trip
                 const bool eval3 = newton && pend_f;
                 double ye[3][3], Fe[3][3];
-                // Z = T W (radau.py:124): Z[2] = W0 + W1
-                const KZ kzp = load_kz(&fresh(pa)->rt);
 #pragma unroll
                 for (int q = 0; q < 3; ++q) {
-                    const double z0 = kzp.T00 * W[0][q] + kzp.T01 * W[1][q] + kzp.T02 * W[2][q];
-                    const double z1 = kzp.T10 * W[0][q] + kzp.T11 * W[1][q] + kzp.T12 * W[2][q];
-                    const double z2 = W[0][q] + W[1][q];
                     double p0 = yc[q];                                        // PH_OUTER_BEGIN, PH_FNEW
                     if (phase == PH_F1) p0 = aux[q];
                     if (phase == PH_ERR_REFINE) p0 = yc[q] + aux[q];
-                    if (newton) p0 = yc[q] + z0;
-                    ye[0][q] = p0; ye[1][q] = yc[q] + z1; ye[2][q] = yc[q] + z2;
+                    ye[0][q] = p0;
                 }
                 bool b0 = false, b1 = false, b2 = false, b3 = false;
                 if (__ballot(newton) != 0ull) {
+                    // Z = T W (radau.py:124): Z[2] = W0 + W1 -- the stage points, formed only on trips that evaluate them
+                    const KZ kzp = load_kz(&fresh(pa)->rt);
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) {
+                        const double z0 = kzp.T00 * W[0][q] + kzp.T01 * W[1][q] + kzp.T02 * W[2][q];
+                        const double z1 = kzp.T10 * W[0][q] + kzp.T11 * W[1][q] + kzp.T12 * W[2][q];
+                        const double z2 = W[0][q] + W[1][q];
+                        if (newton) ye[0][q] = yc[q] + z0;
+                        ye[1][q] = yc[q] + z1; ye[2][q] = yc[q] + z2;
+                    }
                     // some reactor of the wavefront is in its Newton phase: all three stage points (three independent
                     // chains for the scheduler to interleave); the other lanes' slot-1/2 results are simply not used
                     bool bb[3];
