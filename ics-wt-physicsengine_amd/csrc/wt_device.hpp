@@ -2018,9 +2018,8 @@ __device__ __forceinline__ void run_item(ArgPtr pa, const Lane &L, double *lds, 
                     if (phase == PH_ERR_REFINE) p0 = yc[q] + aux[q];
                     ye[0][q] = p0;
                 }
-                bool b0 = false, b1 = false, b2 = false, b3 = false;
-                if (__ballot(newton) != 0ull) {
-                    // Z = T W (radau.py:124): Z[2] = W0 + W1 -- the stage points, formed only on trips that evaluate them
+                // Z = T W (radau.py:124): Z[2] = W0 + W1 -- the stage points
+                auto stage_points = [&]() {
                     const KZ kzp = load_kz(&fresh(pa)->rt);
 #pragma unroll
                     for (int q = 0; q < 3; ++q) {
@@ -2030,6 +2029,13 @@ __device__ __forceinline__ void run_item(ArgPtr pa, const Lane &L, double *lds, 
                         if (newton) ye[0][q] = yc[q] + z0;
                         ye[1][q] = yc[q] + z1; ye[2][q] = yc[q] + z2;
                     }
+                };
+                // formed only on trips that evaluate them (+1 % at n = 8) -- except in the n = 17...32 kernel, which sits
+                // at 512 registers and answers the extra block with a private segment (tests/test_host_api.py)
+                if constexpr (LV >= 5) stage_points();
+                bool b0 = false, b1 = false, b2 = false, b3 = false;
+                if (__ballot(newton) != 0ull) {
+                    if constexpr (LV < 5) stage_points();
                     // some reactor of the wavefront is in its Newton phase: all three stage points (three independent
                     // chains for the scheduler to interleave); the other lanes' slot-1/2 results are simply not used
                     bool bb[3];
