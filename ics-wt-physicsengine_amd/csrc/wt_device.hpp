@@ -837,21 +837,18 @@ __device__ __forceinline__ bool jac_t_dense(const Jac &J)
     return (J.pt[0] != 0.0) || (J.pt[1] != 0.0) || (J.pt[2] != 0.0) || (J.ct[0] != 0.0) || (J.ct[2] != 0.0);
 }
 
-// PCR-factored tridiagonal systems (real and complex shift) live in LDS, not in
-// registers: slot-major [slot][64 lanes] doubles, so lane l of a wavefront touches
-// bank pair (2l, 2l+1) of every slot -- conflict-free ds_read_b64 / ds_write_b64.
-// A factor is written once per (h, J) and read once per solve, so LDS traffic is
-// off the fp64 VALU pipe that bounds this kernel, and the register file keeps
-// room for two wavefronts per SIMD.
-// For n > 8 (LV >= 4) the store outgrows what a wavefront may have of the CU's 160 KiB at four wavefronts per CU
-// (three at n > 32): the first NREG slots (real-shift factors) stay in registers instead.  All of them in LDS
-// means three wavefronts per CU at n = 20 and 0.6x the throughput (measured); all real-shift factors in registers
-// costs scratch spills -- so exactly as many as do not fit (n <= 32).
+// PCR-factored tridiagonal systems (real and complex shift) live in LDS, not in registers: pair-major
+// [pair of slots][64 lanes] 16-byte cells (FStore below), conflict-free ds_read_b128 / ds_write_b128.
+// A factor is written once per (h, J) and read once per solve.
+// For n > 16 (LV >= 5) the store outgrows what a wavefront may have of the CU's 160 KiB at four wavefronts per CU:
+// the first NREG slots (real-shift factors) stay in registers instead.  All of them in LDS means three wavefronts
+// per CU and 0.55-0.6x the throughput (measured at n = 20 and n = 40); all real-shift factors in registers costs
+// scratch spills at n <= 32 -- so there exactly as many as do not fit.
 constexpr int fstore_total_slots(int LV) { return 3 * (2 * LV) + 3 * (4 * LV); }
 constexpr int fstore_lds_slots(int LV)
 {
     if (LV >= 6) return fstore_total_slots(LV) - 3 * (2 * LV);                        // n > 32: the real-shift factors in registers keep four wavefronts per CU (all in LDS: three, scratch-free, 0.55x)
-    const int budget = 40960;                                  // bytes per wavefront at four per CU (n > 16: less the exchange row)
+    const int budget = 40960;                                  // bytes per wavefront at four per CU
     const int fixed = ((RK_UNI * rk_maxr(LV) + rk_lane_doubles(LV) + rk_maxr(LV) + 64 + 1) & ~1) * 8;   // LdsMap: reactor constants, history base, reactor indices, exchange row (F_OFF)
     const int fit = (budget - fixed) / 512;
     return fit < fstore_total_slots(LV) ? fit : fstore_total_slots(LV);
