@@ -5,7 +5,8 @@
 // wavefront per workgroup.  Everything a reactor needs for a whole outer step
 // (state, Radau iterates, Jacobian bands, tridiagonal factors) lives in that
 // segment's registers; the 1-D inter-zone stencil, the tridiagonal solves
-// (parallel cyclic reduction) and the RMS norms are DPP / wavefront shuffles.
+// (parallel cyclic reduction) and the RMS norms are DPP / wavefront shuffles (zone counts that straddle a
+// 16-lane DPP row exchange strides >= 2 through a row of LDS instead: both()).
 // HBM is touched once per work item (a wavefront's reactors advanced by a few outer steps): state in,
 // state + derived out.  Work items come from a device-side queue, so one launch advances the whole
 // ensemble by any number of outer steps and no wavefront waits for a launch boundary; the sensor
@@ -322,7 +323,8 @@ template <int CTRL> __device__ __forceinline__ double dpp_mov(double x)
 
 // ROW = true: n divides 16, so a segment never straddles a 16-lane DPP row and
 // every power-of-two stride is a row shift.  ROW = false: any n <= 64; stride 1
-// is a whole-wave DPP shift, larger strides go through ds_bpermute.
+// is a whole-wave DPP shift; larger strides go through the exchange row (both(), below) in the solver, and
+// through ds_bpermute in these two single-direction forms (self-test only).
 // Values read from outside the segment are unspecified; callers mask them.
 __device__ __forceinline__ double bpermute(int byte_addr, double x)
 {
@@ -373,7 +375,7 @@ template <int D> __device__ __forceinline__ double x_rel(const Lane &L)
 
 // At the top level of the cyclic reduction (stride S = 2^(LV-1) >= n/2) a zone has at most ONE partner: zone z - S if
 // z >= S, else zone z + S if that exists.  ROW kernels (n = 2 S): partner = z xor S, a quad permutation (n = 2, 4), a
-// row rotation (n = 16) or two bank-masked row shifts into one register (n = 8).  Otherwise one ds_bpermute.
+// row rotation (n = 16) or two bank-masked row shifts into one register (n = 8).  Otherwise through the exchange row.
 template <int CTRL, int BANKS> __device__ __forceinline__ double dpp_merge(double old, double x)
 {
     const int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(x), CTRL, 0xf, BANKS, false);
