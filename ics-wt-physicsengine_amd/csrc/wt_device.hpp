@@ -829,6 +829,58 @@ __device__ __forceinline__ bool rhs_full(const Lane &L, const KP &cp, const KT &
 struct Jac {
     double pp[3], cc[3], tt[3], pt[3], ct[3], cp;
 };
+// Loop-carried state that is written rarely and read rarely, held in ACCUMULATION registers by name: the register
+// file of a lone wavefront has 512 registers of which the VALU addresses 256, and what the allocator keeps beyond
+// them it shuffles through `v_accvgpr` copies at the head of the solver loop -- on EVERY trip, whether the value is
+// touched or not.  A value that lives in an AGPR by constraint costs its copies where it is written and where it is
+// read, nothing in between.  (Writes are VALU instructions: under a lane mask they update the active lanes only.)
+// (A = false: an ordinary variable -- the n > 16 kernels sit at 512 registers and answer 74 pinned AGPRs with scratch)
+template <bool A> struct Held;
+template <> struct Held<false> {
+    double v;
+    __device__ __forceinline__ void init() { v = 0.0; }
+    __device__ __forceinline__ void set(double x) { v = x; }
+    __device__ __forceinline__ double get() const { return v; }
+};
+template <> struct Held<true> {
+    int lo, hi;
+    __device__ __forceinline__ void init() { asm volatile("" : "=a"(lo), "=a"(hi)); }     // (defined, value irrelevant)
+    __device__ __forceinline__ void set(double x)
+    {
+        asm volatile("v_accvgpr_write_b32 %0, %2\n\tv_accvgpr_write_b32 %1, %3" : "+a"(lo), "+a"(hi) : "v"(__double2loint(x)), "v"(__double2hiint(x)));
+    }
+    __device__ __forceinline__ double get() const
+    {
+        int l, h;
+        asm("v_accvgpr_read_b32 %0, %2\n\tv_accvgpr_read_b32 %1, %3" : "=v"(l), "=v"(h) : "a"(lo), "a"(hi));
+        return __hiloint2double(h, l);
+    }
+};
+template <bool A> struct JacA {
+    Held<A> e[16];     // tt[3], pp[3], cc[3] | pt[3], ct[3], cp
+    __device__ __forceinline__ void init() {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) e[i].init();
+    }
+    __device__ __forceinline__ void put(const Jac &J)
+    {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) { e[r].set(J.tt[r]); e[3 + r].set(J.pp[r]); e[6 + r].set(J.cc[r]); e[9 + r].set(J.pt[r]); e[12 + r].set(J.ct[r]); }
+        e[15].set(J.cp);
+    }
+    __device__ __forceinline__ void bands(Jac &J) const
+    {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) { J.tt[r] = e[r].get(); J.pp[r] = e[3 + r].get(); J.cc[r] = e[6 + r].get(); }
+    }
+    __device__ __forceinline__ void coupling(Jac &J) const
+    {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) { J.pt[r] = e[9 + r].get(); J.ct[r] = e[12 + r].get(); }
+        J.cp = e[15].get();
+    }
+};
+
 // The inter-zone exchange depends on temperature through the stratification switch only, a step function: unless a
 // finite-difference perturbation happens to flip a switch, the pH rows do not see T at all and the Cl rows see their
 // own zone's T only (the Arrhenius rate) -- exact zeros, column by column.  A wavefront whose lanes all find them zero
@@ -1844,8 +1896,15 @@ __device__ __forceinline__ void run_item(ArgPtr pa, const Lane &L, double *lds, 
             // ================= one IntegratedCSTR.step(): a fresh scipy solver object (reactor.py:476)
             double yc[3], W[3][3];                    // solver's current y; Newton iterate in transformed variables
             double aux[3] = {0, 0, 0};                // y0 + h0 f0 (initial step) / error vector (refinement)
-            double Q[3][3], y_old[3] = {0, 0, 0};     // dense output of the last accepted step
-            Jac J;
+            constexpr bool HELD = LV <= 4;           // (see Held)
+            typedef Held<HELD> AReg64;
+            // dense output of the last accepted step: written when a step is accepted, read when the next attempt is set up
+            AReg64 Qa[3][3], y_old_a[3], sol_t_old_a, sol_h_a;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) { y_old_a[q].init(); Qa[q][0].init(); Qa[q][1].init(); Qa[q][2].init(); }
+            sol_t_old_a.init(); sol_h_a.init();
+            Jac J;                                    // num_jac's output; between its uses the Jacobian lives in `ja`
+            JacA<HELD> ja; ja.init();
             FStore<LV> F;
             F.cell = (LdsDouble2 *)lds_factors + lane;
             uint32_t fl = 1u << 4;                    // current_jac = true
@@ -1855,11 +1914,12 @@ __device__ __forceinline__ void run_item(ArgPtr pa, const Lane &L, double *lds, 
                  limit_hit{fl, 1u << 16}, pend_f{fl, 1u << 17}, jac_after_fnew{fl, 1u << 18},
                  j_dense{fl, 1u << 19};               // this lane's Jacobian couples a row to a neighbour's temperature
             fv = f_valid;
-            double fac[3] = {0, 0, 0};
+            AReg64 fac_a[3]; fac_a[0].init(); fac_a[1].init(); fac_a[2].init();   // num_jac's factors: touched once per Jacobian
             double t = t_out, t_bound = t_out + dt, max_step = fmin(dt, 10.0);
             double h = 0, t_new = 0, h_abs = 0, h_abs_l = 0, min_step = 0;
-            double h_abs_old = 0, err_old = 0, h_abs_old_l = 0, err_old_l = 0;
-            double sol_t_old = 0, sol_h = 1;
+            // the step-size controller's memory: written when a step is accepted / begun, read when the next one is judged
+            AReg64 h_abs_old_a, err_old_a, h_abs_old_l_a, err_old_l_a;
+            h_abs_old_a.init(); err_old_a.init(); h_abs_old_l_a.init(); err_old_l_a.init();
             int kk = 0, n_iter = 0; double dW_norm_old = 0, rate = 0;
             double error_norm = 0, safety = 0;
             double d0 = 0, d1 = 0, h0 = 0;            // select_initial_step
@@ -1870,7 +1930,7 @@ __device__ __forceinline__ void run_item(ArgPtr pa, const Lane &L, double *lds, 
             // jac_after_fnew: that step also asked for a fresh Jacobian (radau.py:500,512)
             int phase = PH_OUTER_BEGIN;
 #pragma unroll
-            for (int q = 0; q < 3; ++q) { yc[q] = y0[q]; W[0][q] = W[1][q] = W[2][q] = 0.0; Q[q][0] = Q[q][1] = Q[q][2] = 0.0; }
+            for (int q = 0; q < 3; ++q) { yc[q] = y0[q]; W[0][q] = W[1][q] = W[2][q] = 0.0; }
 
             // select_initial_step (common.py:68-134), order 3, up to the probe point y0 + h0 f0
             auto initial_step_first_half = [&]() {
@@ -1885,7 +1945,7 @@ __device__ __forceinline__ void run_item(ArgPtr pa, const Lane &L, double *lds, 
             };
             // error_norm > 1: radau.py:489-496
             auto reject_step = [&]() {
-                const double fct = predict_factor(h_abs_l, have_old_l, h_abs_old_l, error_norm, err_old_l);
+                const double fct = predict_factor(h_abs_l, have_old_l, h_abs_old_l_a.get(), error_norm, err_old_l_a.get());
                 h_abs_l *= fmax(MIN_FACTOR, safety * fct);
                 have_lu = false; rejected = true; cnt_s.nrej++;
                 phase = PH_ATTEMPT;
@@ -1895,11 +1955,11 @@ __device__ __forceinline__ void run_item(ArgPtr pa, const Lane &L, double *lds, 
             // step needs it at once, it is evaluated together with the next Newton trip (pend_f).
             auto accept_step = [&]() {
                 const bool recompute_jac = (n_iter > 2) && have_rate && (rate > 1e-3);
-                double fct = predict_factor(h_abs_l, have_old_l, h_abs_old_l, error_norm, err_old_l);
+                double fct = predict_factor(h_abs_l, have_old_l, h_abs_old_l_a.get(), error_norm, err_old_l_a.get());
                 fct = fmin(MAX_FACTOR, safety * fct);
                 if (!recompute_jac && fct < 1.2) fct = 1.0; else have_lu = false;
-                h_abs_old = h_abs;            // sic radau.py:520: the solver-level value
-                err_old = error_norm;
+                h_abs_old_a.set(h_abs);       // sic radau.py:520: the solver-level value
+                err_old_a.set(error_norm);
                 have_old = true;
                 h_abs = h_abs_l * fct;
                 const KZ kz = lit_kz(); const KA ka = lit_ka();
@@ -1908,13 +1968,13 @@ __device__ __forceinline__ void run_item(ArgPtr pa, const Lane &L, double *lds, 
                     const double z0 = kz.T00 * W[0][q] + kz.T01 * W[1][q] + kz.T02 * W[2][q];
                     const double z1 = kz.T10 * W[0][q] + kz.T11 * W[1][q] + kz.T12 * W[2][q];
                     const double z2 = W[0][q] + W[1][q];
-                    y_old[q] = yc[q];
-                    Q[q][0] = z0 * ka.P[0] + z1 * ka.P[3] + z2 * ka.P[6];  // Q = Z^T P  radau.py:541-543
-                    Q[q][1] = z0 * ka.P[1] + z1 * ka.P[4] + z2 * ka.P[7];
-                    Q[q][2] = z0 * ka.P[2] + z1 * ka.P[5] + z2 * ka.P[8];
+                    y_old_a[q].set(yc[q]);
+                    Qa[q][0].set(z0 * ka.P[0] + z1 * ka.P[3] + z2 * ka.P[6]);  // Q = Z^T P  radau.py:541-543
+                    Qa[q][1].set(z0 * ka.P[1] + z1 * ka.P[4] + z2 * ka.P[7]);
+                    Qa[q][2].set(z0 * ka.P[2] + z1 * ka.P[5] + z2 * ka.P[8]);
                     yc[q] = yc[q] + z2;
                 }
-                sol_t_old = t; sol_h = t_new - t; have_sol = true;
+                sol_t_old_a.set(t); sol_h_a.set(t_new - t); have_sol = true;
                 t = t_new;
                 cnt_s.nsteps++; cnt_s.nfev++;     // f(y_new) counted where scipy calls it
                 pend_f = true; fv = false;
@@ -1944,7 +2004,7 @@ __device__ __forceinline__ void run_item(ArgPtr pa, const Lane &L, double *lds, 
                     min_step = 10 * fabs(ulp_above(t));                      // radau.py:408
                     if (h_abs > max_step) { h_abs_l = max_step; have_old_l = false; }
                     else if (h_abs < min_step) { h_abs_l = min_step; have_old_l = false; }
-                    else { h_abs_l = h_abs; have_old_l = have_old; h_abs_old_l = h_abs_old; err_old_l = err_old; }
+                    else { h_abs_l = h_abs; have_old_l = have_old; h_abs_old_l_a.set(h_abs_old_a.get()); err_old_l_a.set(err_old_a.get()); }
                     rejected = false; keep_h = false;
                     phase = PH_ATTEMPT;
                 }
@@ -1971,7 +2031,10 @@ __device__ __forceinline__ void run_item(ArgPtr pa, const Lane &L, double *lds, 
 #pragma unroll
                                 for (int q = 0; q < 3; ++q) Z0[s][q] = 0.0;
                         } else {
-                            const double isol = rcp(sol_h);
+                            const double sol_t_old = sol_t_old_a.get(), isol = rcp(sol_h_a.get());
+                            double Q[3][3], y_old[3];
+#pragma unroll
+                            for (int q = 0; q < 3; ++q) { y_old[q] = y_old_a[q].get(); Q[q][0] = Qa[q][0].get(); Q[q][1] = Qa[q][1].get(); Q[q][2] = Qa[q][2].get(); }
                             const KG kg = load_kg(&fresh(pa)->rt);
                             const double cs[3] = {kg.C0, kg.C1, 1.0};
 #pragma unroll
@@ -1980,7 +2043,8 @@ __device__ __forceinline__ void run_item(ArgPtr pa, const Lane &L, double *lds, 
                                 const double p1 = x * x, p2 = p1 * x;
 #pragma unroll
                                 for (int q = 0; q < 3; ++q)
-                                    Z0[s][q] = ((Q[q][0] * x + Q[q][1] * p1 + Q[q][2] * p2) + y_old[q]) - yc[q];
+                                    // (which products fuse is spelled out: the polynomial's rounding steers Newton's start)
+                                    Z0[s][q] = (__builtin_fma(Q[q][2], p2, __builtin_fma(Q[q][0], x, Q[q][1] * p1)) + y_old[q]) - yc[q];
                             }
                         }
                         const KN kn0 = load_kn(&fresh(pa)->rt);
@@ -1999,7 +2063,7 @@ __device__ __forceinline__ void run_item(ArgPtr pa, const Lane &L, double *lds, 
                 if (__ballot(phase == PH_NEWTON && !have_lu) != 0ull) WT_COUNT(diag_fact);
 #endif
                 if (phase == PH_NEWTON && !have_lu) {
-                    factorize<ROW, LV>(L, J, h, F); have_lu = true; cnt_s.nlu += 2;      // radau.py:454-456
+                    { Jac Jb; ja.bands(Jb); factorize<ROW, LV>(L, Jb, h, F); } have_lu = true; cnt_s.nlu += 2;      // radau.py:454-456
                 }
 
                 WT_STAMP(2);   // factorisation
@@ -2090,6 +2154,7 @@ __device__ __forceinline__ void run_item(ArgPtr pa, const Lane &L, double *lds, 
                     phase = PH_STEP_BEGIN;
                 } else if (phase == PH_NEWTON) {
                     // ---- one iteration of solve_collocation_system radau.py:84-134
+                    Jac Jc; ja.coupling(Jc);
                     bool finite = true;
 #pragma unroll
                     for (int s = 0; s < 3; ++s)
@@ -2113,7 +2178,7 @@ __device__ __forceinline__ void run_item(ArgPtr pa, const Lane &L, double *lds, 
                             fcr[q] = re - (Mcr * W[1][q] - Mci * W[2][q]);
                             fci[q] = im - (Mcr * W[2][q] + Mci * W[1][q]);
                         }
-                        solve_rc<ROW, LV>(L, J, F, fr, fcr, fci, __ballot(j_dense) == 0ull);
+                        solve_rc<ROW, LV>(L, Jc, F, fr, fcr, fci, __ballot(j_dense) == 0ull);
                         double ssum = 0.0;
 #pragma unroll
                         for (int q = 0; q < 3; ++q) {
@@ -2153,7 +2218,7 @@ __device__ __forceinline__ void run_item(ArgPtr pa, const Lane &L, double *lds, 
                             err[q] = f[q] + ZE;
                             esc[q] = kze.atol + fmax(fabs(yc[q]), fabs(yc[q] + z2)) * kze.rtol;
                         }
-                        solve_real<ROW, LV>(L, J, F, err, __ballot(j_dense) == 0ull);
+                        solve_real<ROW, LV>(L, Jc, F, err, __ballot(j_dense) == 0ull);
                         error_norm = rms3<ROW, LV>(L, err, esc);
                         safety = 0.9 * (2 * NEWTON_MAXITER + 1) / (2 * NEWTON_MAXITER + n_iter);
                         if (WT_RARE(rejected && error_norm > 1)) {
@@ -2167,6 +2232,7 @@ __device__ __forceinline__ void run_item(ArgPtr pa, const Lane &L, double *lds, 
                         }
                     }
                 } else if (WT_RARE(phase == PH_ERR_REFINE)) {
+                    Jac Jc; ja.coupling(Jc);
                     double err[3], esc[3];
                     const double ih_e = rcp(h);
                     const KZ kze = lit_kz(); const KE ke = lit_ke();
@@ -2179,7 +2245,7 @@ __device__ __forceinline__ void run_item(ArgPtr pa, const Lane &L, double *lds, 
                         err[q] = Fe[0][q] + ZE;
                         esc[q] = kze.atol + fmax(fabs(yc[q]), fabs(yc[q] + z2)) * kze.rtol;
                     }
-                    solve_real<ROW, LV>(L, J, F, err, __ballot(j_dense) == 0ull);
+                    solve_real<ROW, LV>(L, Jc, F, err, __ballot(j_dense) == 0ull);
                     error_norm = rms3<ROW, LV>(L, err, esc);
                     if (error_norm > 1) reject_step(); else accept_step();
                 } else if (phase == PH_FNEW) {
@@ -2201,9 +2267,12 @@ __device__ __forceinline__ void run_item(ArgPtr pa, const Lane &L, double *lds, 
                 if (need_jac) {
                     bool jbad = false, hf = have_fac, jd = false; double jval = 0;
                     asm volatile("" ::: "memory");               // a fresh fetch: do not keep the constants live across the epilogue
+                    double fac[3] = {fac_a[0].get(), fac_a[1].get(), fac_a[2].get()};
                     num_jac<ROW>(L, ks, [&]() { return &fresh(pa)->kt; }, yc, f, fac, hf, J, jbad, jval, jd); cnt_s.njev++;
+                    fac_a[0].set(fac[0]); fac_a[1].set(fac[1]); fac_a[2].set(fac[2]);
                     have_fac = hf;
                     j_dense = jd;
+                    ja.put(J);
                     need_jac = false;
                     if (WT_RARE(seg_any(L, jbad))) {
                         if (jbad && !bad) { badstage = 4; badval = jval; }
