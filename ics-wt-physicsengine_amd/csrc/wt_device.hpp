@@ -834,7 +834,7 @@ struct Jac {
 // them it shuffles through `v_accvgpr` copies at the head of the solver loop -- on EVERY trip, whether the value is
 // touched or not.  A value that lives in an AGPR by constraint costs its copies where it is written and where it is
 // read, nothing in between.  (Writes are VALU instructions: under a lane mask they update the active lanes only.)
-// (A = false: an ordinary variable -- the n > 16 kernels sit at 512 registers and answer 74 pinned AGPRs with scratch)
+// (A = false: an ordinary variable -- the n > 16 kernels, at 480-512 registers, answer 74 pinned AGPRs with scratch)
 template <bool A> struct Held;
 template <> struct Held<false> {
     double v;
@@ -2093,8 +2093,8 @@ __device__ __forceinline__ void run_item(ArgPtr pa, const Lane &L, double *lds, 
                         ye[1][q] = yc[q] + z1; ye[2][q] = yc[q] + z2;
                     }
                 };
-                // formed only on trips that evaluate them (+1 % at n = 8) -- except in the n = 17...32 kernel, which sits
-                // at 512 registers and answers the extra block with a private segment (tests/test_host_api.py)
+                // formed only on trips that evaluate them (+1 % at n = 8) -- except in the n = 17...32 kernel, where the
+                // extra block measures 0.6 % slower (and, before its solver state was restructured, cost a private segment)
                 if constexpr (LV >= 5) stage_points();
                 bool b0 = false, b1 = false, b2 = false, b3 = false;
                 if (__ballot(newton) != 0ull) {
