@@ -834,7 +834,8 @@ struct Jac {
 // them it shuffles through `v_accvgpr` copies at the head of the solver loop -- on EVERY trip, whether the value is
 // touched or not.  A value that lives in an AGPR by constraint costs its copies where it is written and where it is
 // read, nothing in between.  (Writes are VALU instructions: under a lane mask they update the active lanes only.)
-// (A = false: an ordinary variable -- the n > 16 kernels, at 480-512 registers, answer 74 pinned AGPRs with scratch)
+// (A = false: an ordinary variable -- the n > 16 kernels, at 480-512 registers, answer 74 pinned AGPRs with scratch;
+// the n = 17...32 kernel takes the 42 of everything but the Jacobian)
 template <bool A> struct Held;
 template <> struct Held<false> {
     double v;
@@ -1896,7 +1897,7 @@ __device__ __forceinline__ void run_item(ArgPtr pa, const Lane &L, double *lds, 
             // ================= one IntegratedCSTR.step(): a fresh scipy solver object (reactor.py:476)
             double yc[3], W[3][3];                    // solver's current y; Newton iterate in transformed variables
             double aux[3] = {0, 0, 0};                // y0 + h0 f0 (initial step) / error vector (refinement)
-            constexpr bool HELD = LV <= 4;           // (see Held)
+            constexpr bool HELD = LV <= 5;           // (see Held; the n = 17...32 kernel holds all but the Jacobian: +0.7 %)
             typedef Held<HELD> AReg64;
             // dense output of the last accepted step: written when a step is accepted, read when the next attempt is set up
             AReg64 Qa[3][3], y_old_a[3], sol_t_old_a, sol_h_a;
@@ -1904,7 +1905,7 @@ __device__ __forceinline__ void run_item(ArgPtr pa, const Lane &L, double *lds, 
             for (int q = 0; q < 3; ++q) { y_old_a[q].init(); Qa[q][0].init(); Qa[q][1].init(); Qa[q][2].init(); }
             sol_t_old_a.init(); sol_h_a.init();
             Jac J;                                    // num_jac's output; between its uses the Jacobian lives in `ja`
-            JacA<HELD> ja; ja.init();
+            JacA<(LV <= 4)> ja; ja.init();
             FStore<LV> F;
             F.cell = (LdsDouble2 *)lds_factors + lane;
             uint32_t fl = 1u << 4;                    // current_jac = true
