@@ -896,16 +896,15 @@ __device__ __forceinline__ bool jac_t_dense(const Jac &J)
 // [pair of slots][64 lanes] 16-byte cells (FStore below), conflict-free ds_read_b128 / ds_write_b128.
 // A factor is written once per (h, J) and read once per solve.
 // For n > 16 (LV >= 5) the store outgrows what a wavefront may have of the CU's 160 KiB at four wavefronts per CU:
-// the first NREG slots (real-shift factors) stay in registers instead.  All of them in LDS means three wavefronts
-// per CU and 0.55-0.6x the throughput (measured at n = 20 and n = 40); all real-shift factors in registers costs
-// scratch spills at n <= 32 -- so there exactly as many as do not fit.
+// the first NREG slots (real-shift factors) stay in registers instead -- exactly as many as do not fit.  All of them
+// in LDS means three wavefronts per CU and 0.55-0.6x the throughput (measured at n = 20 and n = 40); all real-shift
+// factors in registers costs scratch spills (n <= 32) or more of them (n > 32: 292 B against 176 B, -1 %).
 constexpr int fstore_total_slots(int LV) { return 3 * (2 * LV) + 3 * (4 * LV); }
 constexpr int fstore_lds_slots(int LV)
 {
-    if (LV >= 6) return fstore_total_slots(LV) - 3 * (2 * LV);                        // n > 32: the real-shift factors in registers keep four wavefronts per CU (all in LDS: three, scratch-free, 0.55x)
     const int budget = 40960;                                  // bytes per wavefront at four per CU
     const int fixed = ((RK_UNI * rk_maxr(LV) + rk_lane_doubles(LV) + rk_maxr(LV) + 64 + 1) & ~1) * 8;   // LdsMap: reactor constants, history base, reactor indices, exchange row (F_OFF)
-    const int fit = (budget - fixed) / 512;
+    const int fit = ((budget - fixed) / 512) & ~1;                 // slots are stored as pairs
     return fit < fstore_total_slots(LV) ? fit : fstore_total_slots(LV);
 }
 typedef double __attribute__((ext_vector_type(2))) double2v;
